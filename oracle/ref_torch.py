@@ -1,0 +1,528 @@
+"""CPU ORACLE — TEST INFRASTRUCTURE, NOT THE PRODUCT.
+
+A plain PyTorch (fp32, CPU) restatement of the reference's pose2vid hot path, written as pure
+functions over flat state-dicts (the reference's own key names).  Only `tests/`,
+`__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this file; the product
+(`aniportrait_amd/`) never does.
+
+What it restates (reference = Zejun-Yang/AniPortrait @ 2024_08_07, paths under /root/reference):
+  * ResnetBlock3D / InflatedConv3d / InflatedGroupNorm      src/models/resnet.py:10-29,218-248
+  * Upsample3D / Downsample3D                                src/models/resnet.py:32-121
+  * Transformer3DModel                                        src/models/transformer_3d.py:103-169
+  * reference-attention block, write + read mode              src/models/mutual_self_attention.py:93-265
+  * VanillaTemporalModule / VersatileAttention / pos-enc      src/models/motion_module.py:44-388
+  * UNet3DConditionModel.forward                              src/models/unet_3d.py:399-580
+  * ReferenceNet (UNet2DConditionModel, conv_out removed)     src/models/unet_2d_condition.py:872-1308
+  * PoseGuider (adjacent, train-mode BatchNorm)               src/models/pose_guider.py:124-162,262-308
+  * sliding-window scheduler                                  src/pipelines/context.py:7-42
+  * Pose2VideoPipeline.__call__ (long + short)                src/pipelines/pipeline_pose2vid_long.py:339-584
+  * third-party arithmetic (diffusers==0.24.0, requirements.txt:5 — NOT vendored in the reference):
+    Attention/AttnProcessor2_0, FeedForward(GEGLU), Timesteps/TimestepEmbedding, ResnetBlock2D,
+    Down/Upsample2D, AutoencoderKL, DDIMScheduler, VaeImageProcessor — restated from the
+    published 0.24.0 behaviour.
+
+Pinning: the reference ships NO tests or golden vectors.  This file is pinned against outputs of
+the reference's own .py files executed in the build container (oracle/ref_harness.py +
+oracle/make_golden.py -> tests/golden/*.pt, checked by tests/test_oracle_golden.py).  Those runs
+sit on a *stub* of diffusers 0.24.0 (oracle/diffusers_stub) because the real wheel is not
+available offline, hence: **parity unpinned at the diffusers boundary**; pinned above it.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+# ----------------------------------------------------------------------------------------------
+# small helpers
+# ----------------------------------------------------------------------------------------------
+
+
+def _lin(sd, p, x):
+    return F.linear(x, sd[p + ".weight"], sd.get(p + ".bias"))
+
+
+def _conv(sd, p, x, stride=1, padding=1):
+    return F.conv2d(x, sd[p + ".weight"], sd.get(p + ".bias"), stride=stride, padding=padding)
+
+
+def _gn(sd, p, x, eps, groups=32):
+    return F.group_norm(x, groups, sd[p + ".weight"], sd[p + ".bias"], eps)
+
+
+def _ln(sd, p, x, eps=1e-5):
+    return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], eps)
+
+
+def timestep_embedding(t, dim=320, flip_sin_to_cos=True, freq_shift=0, max_period=10000):
+    """diffusers `get_timestep_embedding` (unet_3d.py:95,463)."""
+    half = dim // 2
+    exponent = -math.log(max_period) * torch.arange(half, dtype=torch.float32) / (half - freq_shift)
+    emb = t[:, None].float() * torch.exp(exponent)[None, :]
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+    if flip_sin_to_cos:
+        emb = torch.cat([emb[:, half:], emb[:, :half]], dim=-1)
+    return emb
+
+
+def time_embed(sd, t, batch, ch0):
+    t = torch.as_tensor(t).reshape(-1).expand(batch)
+    e = timestep_embedding(t, ch0)
+    return _lin(sd, "time_embedding.linear_2", F.silu(_lin(sd, "time_embedding.linear_1", e)))
+
+
+def mha(sd, p, x, ctx, heads):
+    """diffusers Attention + AttnProcessor2_0: softmax(q k^T / sqrt(d)) v, then to_out[0]."""
+    q = _lin(sd, p + ".to_q", x)
+    k = _lin(sd, p + ".to_k", ctx)
+    v = _lin(sd, p + ".to_v", ctx)
+    B, Tq, C = q.shape
+    d = C // heads
+    q = q.view(B, Tq, heads, d).transpose(1, 2)
+    k = k.view(B, -1, heads, d).transpose(1, 2)
+    v = v.view(B, -1, heads, d).transpose(1, 2)
+    s = torch.matmul(q, k.transpose(-1, -2)) * (d ** -0.5)
+    o = torch.matmul(torch.softmax(s, dim=-1), v)
+    o = o.transpose(1, 2).reshape(B, Tq, C)
+    return _lin(sd, p + ".to_out.0", o)
+
+
+def feed_forward(sd, p, x):
+    """diffusers FeedForward(geglu): Linear(C,8C) -> h*gelu_erf(g) -> Linear(4C,C)."""
+    h, g = _lin(sd, p + ".net.0.proj", x).chunk(2, dim=-1)
+    return _lin(sd, p + ".net.2", h * F.gelu(g))
+
+
+def resnet_block(sd, p, x, temb, eps, groups=32):
+    """resnet.py:218-248 (f folded into the batch) == diffusers ResnetBlock2D."""
+    h = F.silu(_gn(sd, p + ".norm1", x, eps, groups))
+    h = _conv(sd, p + ".conv1", h)
+    if temb is not None and (p + ".time_emb_proj.weight") in sd:
+        h = h + _lin(sd, p + ".time_emb_proj", F.silu(temb))[:, :, None, None]
+    h = F.silu(_gn(sd, p + ".norm2", h, eps, groups))
+    h = _conv(sd, p + ".conv2", h)
+    if (p + ".conv_shortcut.weight") in sd:
+        x = _conv(sd, p + ".conv_shortcut", x, padding=0)
+    return x + h
+
+
+# ----------------------------------------------------------------------------------------------
+# spatial transformer with reference attention
+# ----------------------------------------------------------------------------------------------
+
+
+def transformer_block(sd, p, hs, ehs, heads, mode, bank=None, bank_out=None, n_uncond=0, frames_per_sample=1):
+    """BasicTransformerBlock / TemporalBasicTransformerBlock under ReferenceAttentionControl.
+
+    mode "write"  (mutual_self_attention.py:137-146,230-265): store norm1(x), plain block.
+    mode "read"   (:147-228): keys/values = cat[norm1(x), bank repeated per frame]; the first
+                  `n_uncond` rows of the batch are recomputed with self-only attention (CFG).
+    mode "plain"  un-hacked forward (attention.py:383-445).
+    hs (N, T, C); ehs (N, 1, D) per row; bank (b, T, C) with N == b * frames_per_sample.
+    """
+    nh = _ln(sd, p + ".norm1", hs)
+    if mode == "write":
+        bank_out.append(nh.clone())
+        hs = mha(sd, p + ".attn1", nh, nh, heads) + hs
+    elif mode == "read":
+        bank_fea = bank.unsqueeze(1).repeat(1, frames_per_sample, 1, 1).reshape(-1, *bank.shape[1:])
+        ctx = torch.cat([nh, bank_fea.to(nh.dtype)], dim=1)
+        out = mha(sd, p + ".attn1", nh, ctx, heads) + hs
+        if n_uncond > 0:
+            out = out.clone()
+            out[:n_uncond] = mha(sd, p + ".attn1", nh[:n_uncond], nh[:n_uncond], heads) + hs[:n_uncond]
+        hs = out
+    else:
+        hs = mha(sd, p + ".attn1", nh, nh, heads) + hs
+    if (p + ".attn2.to_q.weight") in sd:
+        hs = mha(sd, p + ".attn2", _ln(sd, p + ".norm2", hs), ehs, heads) + hs
+    hs = feed_forward(sd, p + ".ff", _ln(sd, p + ".norm3", hs)) + hs
+    return hs
+
+
+def spatial_transformer(sd, p, x, ehs, heads, **kw):
+    """Transformer3DModel / Transformer2DModel (transformer_3d.py:103-169): x (N, C, H, W)."""
+    N, C, H, W = x.shape
+    h = _gn(sd, p + ".norm", x, 1e-6)
+    h = _conv(sd, p + ".proj_in", h, padding=0)
+    h = h.permute(0, 2, 3, 1).reshape(N, H * W, -1)
+    h = transformer_block(sd, p + ".transformer_blocks.0", h, ehs, heads, **kw)
+    h = h.reshape(N, H, W, -1).permute(0, 3, 1, 2)
+    h = _conv(sd, p + ".proj_out", h, padding=0)
+    return h + x
+
+
+# ----------------------------------------------------------------------------------------------
+# motion module
+# ----------------------------------------------------------------------------------------------
+
+
+def sinusoidal_pe(d_model, max_len=32):
+    """motion_module.py:262-277."""
+    position = torch.arange(max_len).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model))
+    pe = torch.zeros(1, max_len, d_model)
+    pe[0, :, 0::2] = torch.sin(position * div_term)
+    pe[0, :, 1::2] = torch.cos(position * div_term)
+    return pe
+
+
+def motion_module(sd, p, x, f, heads=8, max_len=32):
+    """VanillaTemporalModule (motion_module.py:146-182,236-259,351-388): x (b*f, C, H, W)."""
+    p = p + ".temporal_transformer"
+    N, C, H, W = x.shape
+    h = _gn(sd, p + ".norm", x, 1e-6)
+    h = h.permute(0, 2, 3, 1).reshape(N, H * W, C)
+    h = _lin(sd, p + ".proj_in", h)
+    bp = p + ".transformer_blocks.0"
+    i = 0
+    while (bp + f".attention_blocks.{i}.to_q.weight") in sd:
+        nh = _ln(sd, bp + f".norms.{i}", h)
+        d = nh.shape[1]
+        t = nh.reshape(N // f, f, d, C).permute(0, 2, 1, 3).reshape(-1, f, C)  # (b d) f c
+        pe_key = bp + f".attention_blocks.{i}.pos_encoder.pe"
+        pe = sd[pe_key] if pe_key in sd else sinusoidal_pe(C, max_len)
+        t = t + pe[:, :f].to(t.dtype)
+        a = mha(sd, bp + f".attention_blocks.{i}", t, t, heads)
+        a = a.reshape(N // f, d, f, C).permute(0, 2, 1, 3).reshape(N, d, C)
+        h = a + h
+        i += 1
+    h = feed_forward(sd, bp + ".ff", _ln(sd, bp + ".ff_norm", h)) + h
+    h = _lin(sd, p + ".proj_out", h)
+    h = h.reshape(N, H, W, C).permute(0, 3, 1, 2)
+    return h + x
+
+
+# ----------------------------------------------------------------------------------------------
+# UNets
+# ----------------------------------------------------------------------------------------------
+
+_DOWN_HAS_ATTN = (True, True, True, False)
+_UP_HAS_ATTN = (False, True, True, True)
+
+
+def _unet_body(sd, cfg, x, emb, ehs_rows, f, mode, banks, n_uncond, pose_fea, with_motion):
+    """Shared SD-1.5 topology walk (unet_3d.py:484-570 / unet_2d_condition.py:1136-1296).
+
+    x (N, 4, h, w) with N = b*f; ehs_rows (N, 1, D); banks: dict path -> tensor (read) or list (write).
+    """
+    heads = cfg["attention_head_dim"]
+    eps = cfg["norm_eps"]
+    nblk = len(cfg["block_out_channels"])
+    lpb = cfg["layers_per_block"]
+    b = x.shape[0] // f
+
+    def attn(path, x):
+        kw = dict(mode=mode)
+        if mode == "read":
+            kw.update(bank=banks[path], n_uncond=n_uncond, frames_per_sample=f)
+        elif mode == "write":
+            lst = []
+            kw.update(bank_out=lst)
+        out = spatial_transformer(sd, path, x, ehs_rows, heads, **kw)
+        if mode == "write":
+            banks[path] = lst[0]
+        return out
+
+    def mm(path, x):
+        if with_motion and (path + ".temporal_transformer.proj_in.weight") in sd:
+            return motion_module(sd, path, x, f)
+        return x
+
+    def add_pose(x, i):
+        if pose_fea is None:
+            return x
+        pf = pose_fea[i]  # (b, C, f, h, w)
+        return x + pf.permute(0, 2, 1, 3, 4).reshape(x.shape)
+
+    temb = emb.repeat_interleave(f, dim=0) if emb.shape[0] != x.shape[0] else emb
+    x = _conv(sd, "conv_in", x)
+    x = add_pose(x, 0)
+    skips = [x]
+    for i in range(nblk):
+        for j in range(lpb):
+            x = resnet_block(sd, f"down_blocks.{i}.resnets.{j}", x, temb, eps)
+            if _DOWN_HAS_ATTN[i]:
+                x = attn(f"down_blocks.{i}.attentions.{j}", x)
+            x = mm(f"down_blocks.{i}.motion_modules.{j}", x)
+            skips.append(x)
+        if i != nblk - 1:
+            x = _conv(sd, f"down_blocks.{i}.downsamplers.0.conv", x, stride=2, padding=1)
+            skips.append(x)
+        x = add_pose(x, i + 1)
+    x = resnet_block(sd, "mid_block.resnets.0", x, temb, eps)
+    x = attn("mid_block.attentions.0", x)
+    x = mm("mid_block.motion_modules.0", x)
+    x = resnet_block(sd, "mid_block.resnets.1", x, temb, eps)
+    for i in range(nblk):
+        for j in range(lpb + 1):
+            x = torch.cat([x, skips.pop()], dim=1)
+            x = resnet_block(sd, f"up_blocks.{i}.resnets.{j}", x, temb, eps)
+            if _UP_HAS_ATTN[i]:
+                x = attn(f"up_blocks.{i}.attentions.{j}", x)
+            x = mm(f"up_blocks.{i}.motion_modules.{j}", x)
+        if i != nblk - 1:
+            x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+            x = _conv(sd, f"up_blocks.{i}.upsamplers.0.conv", x)
+    return x
+
+
+def unet3d_forward(sd, cfg, sample, t, ehs, pose_fea=None, banks=None, do_cfg=True):
+    """UNet3DConditionModel.forward (unet_3d.py:399-580). sample (b,4,f,h,w); ehs (b,1,D).
+    banks: dict path -> (b,T,C) (already fp16-rounded) or None for the un-hacked block."""
+    b, c, f, h, w = sample.shape
+    x = sample.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)
+    emb = time_embed(sd, t, b, cfg["block_out_channels"][0])
+    ehs_rows = ehs.repeat_interleave(f, dim=0)
+    mode = "read" if banks is not None else "plain"
+    n_uncond = (b * f) // 2 if (do_cfg and banks is not None) else 0
+    x = _unet_body(sd, cfg, x, emb, ehs_rows, f, mode, banks, n_uncond, pose_fea, True)
+    x = F.silu(_gn(sd, "conv_norm_out", x, cfg["norm_eps"]))
+    x = _conv(sd, "conv_out", x)
+    return x.reshape(b, f, -1, h, w).permute(0, 2, 1, 3, 4)
+
+
+def refnet_forward(sd, cfg, sample, t, ehs, bank_dtype=torch.float16):
+    """ReferenceNet pass in write mode; returns dict path -> bank (b,T,C), rounded through
+    `bank_dtype` as `ReferenceAttentionControl.update` does (mutual_self_attention.py:302,338)."""
+    b = sample.shape[0]
+    emb = time_embed(sd, t, b, cfg["block_out_channels"][0])
+    banks = {}
+    _unet_body(sd, cfg, sample, emb, ehs, 1, "write", banks, 0, None, False)
+    return {k: v.to(bank_dtype).to(v.dtype) for k, v in banks.items()}
+
+
+# ----------------------------------------------------------------------------------------------
+# VAE (diffusers AutoencoderKL, sd-vae-ft-mse topology)
+# ----------------------------------------------------------------------------------------------
+
+
+def _vae_mid(sd, p, x):
+    x = resnet_block(sd, p + ".resnets.0", x, None, 1e-6)
+    N, C, H, W = x.shape
+    a = p + ".attentions.0"
+    t = _gn(sd, a + ".group_norm", x.reshape(N, C, H * W), 1e-6).transpose(1, 2)
+    o = mha(sd, a, t, t, 1)
+    x = o.transpose(1, 2).reshape(N, C, H, W) + x
+    return resnet_block(sd, p + ".resnets.1", x, None, 1e-6)
+
+
+def vae_decode(sd, cfg, z):
+    """AutoencoderKL.decode(z).sample (pipeline_pose2vid_long.py:119-120)."""
+    nb = len(cfg["block_out_channels"])
+    x = _conv(sd, "post_quant_conv", z, padding=0)
+    x = _conv(sd, "decoder.conv_in", x)
+    x = _vae_mid(sd, "decoder.mid_block", x)
+    for i in range(nb):
+        for j in range(cfg["layers_per_block"] + 1):
+            x = resnet_block(sd, f"decoder.up_blocks.{i}.resnets.{j}", x, None, 1e-6)
+        if i != nb - 1:
+            x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+            x = _conv(sd, f"decoder.up_blocks.{i}.upsamplers.0.conv", x)
+    x = F.silu(_gn(sd, "decoder.conv_norm_out", x, 1e-6))
+    return _conv(sd, "decoder.conv_out", x)
+
+
+def vae_encode_mean(sd, cfg, x):
+    """AutoencoderKL.encode(x).latent_dist.mean (pipeline_pose2vid_long.py:430)."""
+    nb = len(cfg["block_out_channels"])
+    x = _conv(sd, "encoder.conv_in", x)
+    for i in range(nb):
+        for j in range(cfg["layers_per_block"]):
+            x = resnet_block(sd, f"encoder.down_blocks.{i}.resnets.{j}", x, None, 1e-6)
+        if i != nb - 1:
+            x = F.pad(x, (0, 1, 0, 1))
+            x = _conv(sd, f"encoder.down_blocks.{i}.downsamplers.0.conv", x, stride=2, padding=0)
+    x = _vae_mid(sd, "encoder.mid_block", x)
+    x = F.silu(_gn(sd, "encoder.conv_norm_out", x, 1e-6))
+    x = _conv(sd, "encoder.conv_out", x)
+    x = _conv(sd, "quant_conv", x, padding=0)
+    return x[:, : cfg["latent_channels"]]
+
+
+# ----------------------------------------------------------------------------------------------
+# PoseGuider (adjacent to the hot path; BatchNorm in TRAIN mode as the scripts leave it)
+# ----------------------------------------------------------------------------------------------
+
+
+def _bn_train(sd, p, x, eps=1e-5):
+    mean = x.mean(dim=(0, 2, 3), keepdim=True)
+    var = x.var(dim=(0, 2, 3), unbiased=False, keepdim=True)
+    return (x - mean) / torch.sqrt(var + eps) * sd[p + ".weight"][None, :, None, None] + sd[p + ".bias"][None, :, None, None]
+
+
+_PG_STACKS = {
+    "conv_layers": [(1, 1), (2, 1), (1, 1), (2, 1), (1, 1), (2, 1), (1, 1), (1, 1)],
+    "conv_layers_1": [(1, 1), (2, 1)],
+    "conv_layers_2": [(1, 1), (2, 1)],
+    "conv_layers_3": [(1, 1), (2, 1)],
+    "conv_layers_4": [(1, 1)],
+}
+
+
+def _pg_stack(sd, name, x):
+    for k, (stride, pad) in enumerate(_PG_STACKS[name]):
+        x = F.conv2d(x, sd[f"{name}.{3 * k}.weight"], sd[f"{name}.{3 * k}.bias"], stride=stride, padding=pad)
+        x = F.relu(_bn_train(sd, f"{name}.{3 * k + 1}", x))
+    return x
+
+
+def _pg_attn(sd, p, x):
+    """pose_guider.Transformer2DModel (pose_guider.py:262-308): 16 heads x 88, no cross-attn."""
+    N, C, H, W = x.shape
+    h = _gn(sd, p + ".norm", x, 1e-6)
+    h = _conv(sd, p + ".proj_in", h, padding=0).permute(0, 2, 3, 1).reshape(N, H * W, -1)
+    h = transformer_block(sd, p + ".transformer_blocks.0", h, None, 16, "plain")
+    h = h.reshape(N, H, W, -1).permute(0, 3, 1, 2)
+    return _conv(sd, p + ".proj_out", h, padding=0) + x
+
+
+def pose_guider(sd, x, ref_x):
+    """PoseGuider.forward (pose_guider.py:124-162). x (b,3,f,H,W) -> list of 5 (b,C,f,h,w).
+    `ref_x` only feeds branches whose result is discarded (cross_attention_dim=None), but its
+    BatchNorm passes do not touch x, so it is ignored here."""
+    b, c, f, H, W = x.shape
+    x = x.permute(0, 2, 1, 3, 4).reshape(b * f, c, H, W)
+
+    def out(t):
+        return t.reshape(b, f, *t.shape[1:]).permute(0, 2, 1, 3, 4)
+
+    fea = []
+    x = _pg_stack(sd, "conv_layers", x)
+    x = _conv(sd, "final_proj", x, padding=0) * sd["scale"]
+    fea.append(out(x))
+    for i in range(1, 5):
+        x = _pg_stack(sd, f"conv_layers_{i}", x)
+        x = _pg_attn(sd, f"cross_attn{i}", x)
+        fea.append(out(x))
+    return fea
+
+
+# ----------------------------------------------------------------------------------------------
+# scheduler / windows / image pre-processing / pipeline
+# ----------------------------------------------------------------------------------------------
+
+
+def ddim_tables(num_train=1000, beta_start=0.00085, beta_end=0.012, rescale_zero_snr=True):
+    """alphas_cumprod of diffusers DDIMScheduler with inference_v2.yaml:24-33."""
+    betas = torch.linspace(beta_start, beta_end, num_train, dtype=torch.float32)
+    if rescale_zero_snr:
+        abar_sqrt = torch.cumprod(1.0 - betas, 0).sqrt()
+        a0, aT = abar_sqrt[0].clone(), abar_sqrt[-1].clone()
+        abar_sqrt = (abar_sqrt - aT) * (a0 / (a0 - aT))
+        abar = abar_sqrt ** 2
+        alphas = torch.cat([abar[0:1], abar[1:] / abar[:-1]])
+        betas = 1 - alphas
+    return torch.cumprod(1.0 - betas, 0)
+
+
+def ddim_timesteps(steps, num_train=1000):
+    """timestep_spacing == "trailing"."""
+    return (np.round(np.arange(num_train, 0, -num_train / steps)).astype(np.int64) - 1).tolist()
+
+
+def ddim_step_v(acp, t, steps, model_output, sample, num_train=1000):
+    """DDIMScheduler.step, v-prediction, eta=0, clip_sample False, set_alpha_to_one True."""
+    prev_t = t - num_train // steps
+    a_t = acp[t]
+    a_prev = acp[prev_t] if prev_t >= 0 else torch.tensor(1.0)
+    b_t = 1 - a_t
+    x0 = (a_t ** 0.5) * sample - (b_t ** 0.5) * model_output
+    eps = (a_t ** 0.5) * model_output + (b_t ** 0.5) * sample
+    return a_prev ** 0.5 * x0 + (1 - a_prev) ** 0.5 * eps
+
+
+def _ordered_halving(val):
+    return int(f"{val:064b}"[::-1], 2) / (1 << 64)
+
+
+def uniform_windows(step, num_frames, context_size=16, context_stride=1, context_overlap=4, closed_loop=True):
+    """context.py:15-42."""
+    if num_frames <= context_size:
+        return [list(range(num_frames))]
+    context_stride = min(context_stride, int(np.ceil(np.log2(num_frames / context_size))) + 1)
+    out = []
+    for context_step in 1 << np.arange(context_stride):
+        pad = int(round(num_frames * _ordered_halving(step)))
+        for j in range(int(_ordered_halving(step) * context_step) + pad,
+                       num_frames + pad + (0 if closed_loop else -context_overlap),
+                       (context_size * context_step - context_overlap)):
+            out.append([e % num_frames for e in range(j, j + context_size * context_step, context_step)])
+    return out
+
+
+def preprocess_pil(img, height, width):
+    """VaeImageProcessor.preprocess, PIL path: RGB, lanczos, /255, NCHW, 2x-1."""
+    import PIL.Image
+    img = img.convert("RGB").resize((width - width % 8, height - height % 8), resample=PIL.Image.LANCZOS)
+    arr = np.array(img).astype(np.float32) / 255.0
+    return 2.0 * torch.from_numpy(arr.transpose(2, 0, 1))[None] - 1.0
+
+
+def preprocess_np(arr, height, width):
+    """VaeImageProcessor.preprocess, numpy path (pose images): NO /255."""
+    t = torch.from_numpy(np.asarray(arr)[None].transpose(0, 3, 1, 2))
+    t = F.interpolate(t, size=(height - height % 8, width - width % 8))
+    return 2.0 * t - 1.0
+
+
+@torch.no_grad()
+def pose2vid(sds, cfgs, clip_embeds, ref_image, pose_images, ref_pose_image, width, height, video_length,
+             num_inference_steps, guidance_scale, latents, context_frames=16, context_stride=1,
+             context_overlap=4, long=True, return_latents=False, progress=None):
+    """Pose2VideoPipeline.__call__ restated (pipeline_pose2vid_long.py:339-584; short variant
+    pipeline_pose2vid.py:286-468 when long=False).
+
+    sds: {"denoising_unet","reference_unet","vae","pose_guider"} -> state-dict (fp32);
+    cfgs: {"unet","vae"}; clip_embeds (1, D) = image_encoder(...).image_embeds;
+    latents (1,4,L,h,w) fp32 initial noise (init_noise_sigma == 1).
+    """
+    do_cfg = guidance_scale > 1.0
+    ucfg = cfgs["unet"]
+    ehs = clip_embeds.unsqueeze(1)
+    if do_cfg:
+        ehs = torch.cat([torch.zeros_like(ehs), ehs], dim=0)
+    nb = 2 if do_cfg else 1
+    ref_lat = vae_encode_mean(sds["vae"], cfgs["vae"], preprocess_pil(ref_image, height, width)) * 0.18215
+    pose = torch.cat([preprocess_np(p, height, width).unsqueeze(2) for p in pose_images], dim=2).float()
+    ref_pose = preprocess_np(ref_pose_image, height, width).float()
+    acp = ddim_tables()
+    timesteps = ddim_timesteps(num_inference_steps)
+    banks = refnet_forward(sds["reference_unet"], ucfg, ref_lat.repeat(nb, 1, 1, 1), 0, ehs)
+    L = latents.shape[2]
+    windows = uniform_windows(0, L, context_frames, context_stride, context_overlap) if long else [list(range(L))]
+    pose_cache = {}
+    for t in timesteps:
+        noise_pred = torch.zeros(nb, *latents.shape[1:])
+        counter = torch.zeros(1, 1, L, 1, 1)
+        for wi, c in enumerate(windows):
+            lat_in = latents[:, :, c].repeat(nb, 1, 1, 1, 1)
+            if wi not in pose_cache:  # the reference recomputes this every step; it is t-independent
+                pose_cache[wi] = pose_guider(sds["pose_guider"], pose[:, :, c].repeat(nb, 1, 1, 1, 1), ref_pose)
+            pred = unet3d_forward(sds["denoising_unet"], ucfg, lat_in, t, ehs[:nb], pose_cache[wi], banks, do_cfg)
+            noise_pred[:, :, c] = noise_pred[:, :, c] + pred
+            counter[:, :, c] = counter[:, :, c] + 1
+            if progress is not None:
+                progress()
+        if do_cfg:
+            u, cnd = (noise_pred / counter).chunk(2)
+            noise_pred = u + guidance_scale * (cnd - u)
+        latents = ddim_step_v(acp, t, num_inference_steps, noise_pred, latents)
+    if return_latents:
+        return latents
+    return decode_latents(sds["vae"], cfgs["vae"], latents)
+
+
+@torch.no_grad()
+def decode_latents(vae_sd, vae_cfg, latents):
+    """pipeline_pose2vid_long.py:113-126."""
+    b, c, f, h, w = latents.shape
+    z = (1 / 0.18215 * latents).permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)
+    frames = torch.cat([vae_decode(vae_sd, vae_cfg, z[i:i + 1]) for i in range(z.shape[0])])
+    video = frames.reshape(b, f, *frames.shape[1:]).permute(0, 2, 1, 3, 4)
+    return (video / 2 + 0.5).clamp(0, 1).float()
+
+
+def psnr(a, b, peak=1.0):
+    mse = torch.mean((a.double() - b.double()) ** 2).item()
+    return float("inf") if mse == 0 else 10.0 * math.log10(peak * peak / mse)
