@@ -1,0 +1,100 @@
+"""ctypes binding of libaniportrait_hip.so (the C ABI declared in include/aniportrait_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails, this module
+raises.  `load()` only dlopens and checks the exported symbols (works without a GPU);
+compute entry points need a gfx950 device.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libaniportrait_hip.so")
+ABI_VERSION = 1
+
+c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class GemmParams(C.Structure):
+    """mirror of `struct anip_gemm_params`"""
+    _fields_ = [
+        ("A", c_void_p), ("lda", c_int64),
+        ("A2", c_void_p), ("lda2", c_int64), ("K1", c_int),
+        ("W", c_void_p), ("ldw", c_int64),
+        ("out", c_void_p), ("ldo", c_int64),
+        ("out_f32", c_int),
+        ("M", c_int), ("N", c_int), ("K", c_int),
+        ("alpha", c_float),
+        ("bias", c_void_p),
+        ("rowbias", c_void_p), ("rows_per_group", c_int64), ("ld_rowbias", c_int64),
+        ("residual", c_void_p), ("ldr", c_int64),
+        ("act", c_int),
+        ("batch", c_int), ("strideA", c_int64), ("strideW", c_int64), ("strideO", c_int64),
+        ("conv", c_int), ("Nimg", c_int), ("Hin", c_int), ("Win", c_int), ("Cin", c_int),
+        ("Hout", c_int), ("Wout", c_int), ("stride", c_int), ("pad", c_int), ("upsample", c_int),
+    ]
+
+
+# name -> (restype, argtypes); must list every symbol declared in include/aniportrait_hip.h
+SIGNATURES = {
+    "anip_version": (c_int, []),
+    "anip_last_error": (C.c_char_p, []),
+    "anip_device_info": (c_int, [C.c_char_p, c_int, C.POINTER(c_int)]),
+    "anip_groupnorm_ws_floats": (c_int64, [c_int, c_int64, c_int, c_int]),
+    "anip_groupnorm": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64,
+                               c_int, c_float, c_int, c_void_p, c_void_p]),
+    "anip_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_int64,
+                               c_int, c_void_p]),
+    "anip_gemm": (c_int, [C.POINTER(GemmParams), c_void_p]),
+    "anip_conv_small": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                c_int, c_void_p]),
+    "anip_ref_attention": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                   c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int,
+                                   c_float, c_void_p]),
+    "anip_temporal_attention": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "anip_softmax_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "anip_linear_small": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "anip_add": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "anip_window_accumulate": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64,
+                                       c_void_p]),
+    "anip_cfg_ddim_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_float, c_float,
+                                   c_float, c_float, c_float, c_void_p]),
+    "anip_ncfhw_to_nhwc": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_void_p]),
+    "anip_nhwc_to_ncfhw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_float, c_float, c_int,
+                                   c_void_p]),
+}
+
+_lib = None
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library and bind every declared symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryError(
+            f"{LIB_PATH} not found: build it with `python -m aniportrait_amd.build` (hipcc, gfx950). "
+            "There is no CPU or PyTorch fallback for the hot path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise HipLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    v = lib.anip_version()
+    if v != ABI_VERSION:
+        raise HipLibraryError(f"ABI version mismatch: library {v}, binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().anip_last_error()
+        raise HipLibraryError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

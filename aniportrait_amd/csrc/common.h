@@ -1,0 +1,57 @@
+// Shared device/host helpers for libaniportrait_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/aniportrait_hip.h"
+
+typedef _Float16 f16;
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+void anip_set_error(const char* fmt, ...);
+
+#define ANIP_REQUIRE(cond, ...)        \
+  do {                                 \
+    if (!(cond)) {                     \
+      anip_set_error(__VA_ARGS__);     \
+      return -1;                       \
+    }                                  \
+  } while (0)
+
+#define ANIP_LAUNCH_CHECK(name)                                              \
+  do {                                                                       \
+    hipError_t e__ = hipGetLastError();                                      \
+    if (e__ != hipSuccess) {                                                 \
+      anip_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return -2;                                                             \
+    }                                                                        \
+  } while (0)
+
+// NOTE: native ext_vector types only — selects on HIP's struct uint4 are lowered through scratch.
+union U4H8 {
+  u32x4 u;
+  f16x8 h;
+  f16 e[8];
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,295 @@
+// Small / HBM-bound kernels for gfx950: direct convolution for tiny channel counts, M<=16 dense
+// layers, residual add, sliding-window accumulation, fused CFG + DDIM(v-prediction) update, and the
+// boundary layout conversions between (B,C,F,H,W) and channels-last frames.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// ---------------------------------------------------------------------------------------------
+// direct conv, Cin <= 8 (conv_in, post_quant_conv). Weights cached in LDS (fp16).
+// thread -> (pixel, group of 8 output channels)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void conv_small_kernel(const f16* __restrict__ x, const f16* __restrict__ w,
+                                                       const float* __restrict__ bias, const f16* __restrict__ res,
+                                                       f16* __restrict__ y, int N, int H, int W, int Cin, int Cout,
+                                                       int ks, int pix_per_block) {
+  extern __shared__ __attribute__((aligned(16))) f16 sw[];  // [Cout][ks*ks*Cin]
+  const int tid = threadIdx.x;
+  const int KK = ks * ks * Cin;
+  for (int i = tid; i < Cout * KK; i += NT) sw[i] = w[i];
+  __syncthreads();
+  const int cg_n = (Cout + 7) / 8;
+  const int64_t npix = (int64_t)N * H * W;
+  const int64_t pix0 = (int64_t)blockIdx.x * pix_per_block;
+  const int pad = ks / 2;
+  for (int o = tid; o < pix_per_block * cg_n; o += NT) {
+    const int pl = o / cg_n, cg = o - pl * cg_n;
+    const int64_t pix = pix0 + pl;
+    if (pix >= npix) continue;
+    const int xw = (int)(pix % W);
+    const int yh = (int)((pix / W) % H);
+    const int64_t img = pix / ((int64_t)W * H);
+    float acc[8];
+    const int co0 = cg * 8;
+    const int nco = min(8, Cout - co0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = (bias != nullptr && e < nco) ? bias[co0 + e] : 0.f;
+    for (int ky = 0; ky < ks; ++ky) {
+      const int iy = yh + ky - pad;
+      if (iy < 0 || iy >= H) continue;
+      for (int kx = 0; kx < ks; ++kx) {
+        const int ix = xw + kx - pad;
+        if (ix < 0 || ix >= W) continue;
+        const f16* xp = x + ((img * H + iy) * W + ix) * Cin;
+        const int wk = (ky * ks + kx) * Cin;
+        for (int ci = 0; ci < Cin; ++ci) {
+          const float xv = (float)xp[ci];
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (e < nco) acc[e] += xv * (float)sw[(co0 + e) * KK + wk + ci];
+        }
+      }
+    }
+    f16* yp = y + pix * Cout + co0;
+    const f16* rp = res ? res + pix * Cout + co0 : nullptr;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (e < nco) {
+        float v = acc[e];
+        if (rp) v += (float)rp[e];
+        yp[e] = (f16)v;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// y[m][n] = sum_k f(x[m][k]) W[n][k] + b[n], M <= 16; one wave per output column n
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void linear_small_kernel(const float* __restrict__ x, const f16* __restrict__ W,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int M,
+                                                         int N, int K, int silu_in) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float acc[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) acc[m] = 0.f;
+  for (int k = lane * 8; k < K; k += 64 * 8) {
+    U4H8 wv;
+    wv.u = *(const u32x4*)(W + (int64_t)n * K + k);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      if (m < M) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float xv = x[(int64_t)m * K + k + e];
+          if (silu_in) xv = silu_f(xv);
+          acc[m] += xv * (float)wv.e[e];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    if (m < M) {
+      const float s = wave_sum(acc[m]);
+      if (lane == 0) y[(int64_t)m * N + n] = s + (bias ? bias[n] : 0.f);
+    }
+  }
+}
+
+__global__ __launch_bounds__(NT) void add_kernel(const f16* __restrict__ a, const f16* __restrict__ b,
+                                                f16* __restrict__ o, int64_t nvec, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * NT;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < nvec; i += stride) {
+    U4H8 x, y2, r;
+    x.u = ((const u32x4*)a)[i];
+    y2.u = ((const u32x4*)b)[i];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r.e[e] = (f16)((float)x.e[e] + (float)y2.e[e]);
+    ((u32x4*)o)[i] = r.u;
+  }
+  // tail
+  if (blockIdx.x == 0) {
+    for (int64_t i = nvec * 8 + threadIdx.x; i < n; i += NT) o[i] = (f16)((float)a[i] + (float)b[i]);
+  }
+}
+
+// acc[s][frames[j]][e] += pred[s][j][e]; counter[frames[j]] += 1 (one thread block column for counters)
+__global__ __launch_bounds__(NT) void window_accumulate_kernel(const f16* __restrict__ pred, float* __restrict__ acc,
+                                                              float* __restrict__ counter,
+                                                              const int* __restrict__ frames, int S, int Fw, int L,
+                                                              int64_t HWC) {
+  const int64_t total = (int64_t)S * Fw * HWC;
+  const int64_t stride = (int64_t)gridDim.x * NT;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += stride) {
+    const int64_t e = i % HWC;
+    const int64_t sj = i / HWC;
+    const int j = (int)(sj % Fw);
+    const int s = (int)(sj / Fw);
+    const int f = frames[j];
+    acc[((int64_t)s * L + f) * HWC + e] += (float)pred[i];
+  }
+  if (blockIdx.x == 0 && threadIdx.x < Fw) counter[frames[threadIdx.x]] += 1.0f;
+}
+
+__global__ __launch_bounds__(NT) void cfg_ddim_kernel(const float* __restrict__ acc, const float* __restrict__ counter,
+                                                     float* __restrict__ lat, f16* __restrict__ lat16, int S, int L,
+                                                     int64_t HWC, float g, float sa, float sb, float sap, float sbp) {
+  const int64_t total = (int64_t)L * HWC;
+  const int64_t stride = (int64_t)gridDim.x * NT;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += stride) {
+    const int f = (int)(i / HWC);
+    float v;
+    if (S == 2) {
+      const float c = counter[f];
+      const float u = acc[i] / c, cd = acc[total + i] / c;
+      v = u + g * (cd - u);
+    } else {
+      v = acc[i];  // reference quirk: no division by the counter without CFG
+    }
+    const float x = lat[i];
+    const float x0 = sa * x - sb * v;
+    const float ep = sa * v + sb * x;
+    const float xn = sap * x0 + sbp * ep;
+    lat[i] = xn;
+    if (lat16) lat16[i] = (f16)xn;
+  }
+}
+
+template <typename TS>
+__global__ __launch_bounds__(NT) void ncfhw_to_nhwc_kernel(const TS* __restrict__ src, f16* __restrict__ dst, int B,
+                                                          int C, int F, int64_t HW) {
+  const int64_t total = (int64_t)B * F * HW * C;
+  const int64_t stride = (int64_t)gridDim.x * NT;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % C);
+    int64_t r = i / C;
+    const int64_t p = r % HW;
+    r /= HW;
+    const int f = (int)(r % F);
+    const int b = (int)(r / F);
+    dst[i] = (f16)(float)src[(((int64_t)b * C + c) * F + f) * HW + p];
+  }
+}
+
+template <typename TD>
+__global__ __launch_bounds__(NT) void nhwc_to_ncfhw_kernel(const f16* __restrict__ src, TD* __restrict__ dst, int B,
+                                                          int C, int F, int64_t HW, float scale, float shift,
+                                                          int clamp01) {
+  const int64_t total = (int64_t)B * F * HW * C;
+  const int64_t stride = (int64_t)gridDim.x * NT;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < total; i += stride) {
+    // i indexes dst (b, c, f, p)
+    const int64_t p = i % HW;
+    int64_t r = i / HW;
+    const int f = (int)(r % F);
+    r /= F;
+    const int c = (int)(r % C);
+    const int b = (int)(r / C);
+    float v = (float)src[(((int64_t)b * F + f) * HW + p) * C + c] * scale + shift;
+    if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+    dst[i] = (TD)v;
+  }
+}
+
+inline unsigned grid_for(int64_t work) {
+  int64_t b = (work + NT - 1) / NT;
+  if (b < 1) b = 1;
+  if (b > 256 * 16) b = 256 * 16;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int anip_conv_small(const void* x, const void* w, const float* bias, const void* residual, void* y, int N,
+                               int H, int W, int Cin, int Cout, int ksize, void* stream) {
+  ANIP_REQUIRE(x && w && y, "anip_conv_small: null pointer");
+  ANIP_REQUIRE(ksize == 1 || ksize == 3, "anip_conv_small: ksize must be 1 or 3");
+  ANIP_REQUIRE(Cin >= 1 && Cin <= 8, "anip_conv_small: Cin=%d must be in [1,8]", Cin);
+  const size_t lds = (size_t)Cout * ksize * ksize * Cin * sizeof(f16);
+  ANIP_REQUIRE(lds <= 65536, "anip_conv_small: weights (%zu B) do not fit in LDS", lds);
+  const int cg_n = (Cout + 7) / 8;
+  int ppb = (NT * 8) / cg_n;  // ~8 outputs groups per thread
+  if (ppb < 1) ppb = 1;
+  if (ppb > 1024) ppb = 1024;
+  const int64_t npix = (int64_t)N * H * W;
+  const int64_t blocks = cdiv64(npix, ppb);
+  hipLaunchKernelGGL(conv_small_kernel, dim3((unsigned)blocks), dim3(NT), lds, (hipStream_t)stream, (const f16*)x,
+                     (const f16*)w, bias, (const f16*)residual, (f16*)y, N, H, W, Cin, Cout, ksize, ppb);
+  ANIP_LAUNCH_CHECK("anip_conv_small");
+  return 0;
+}
+
+extern "C" int anip_linear_small(const float* x, const void* W, const float* bias, float* y, int M, int N, int K,
+                                 int silu_in, void* stream) {
+  ANIP_REQUIRE(x && W && y, "anip_linear_small: null pointer");
+  ANIP_REQUIRE(M >= 1 && M <= 16, "anip_linear_small: M=%d must be in [1,16]", M);
+  ANIP_REQUIRE((K & 7) == 0, "anip_linear_small: K=%d must be a multiple of 8", K);
+  const int blocks = (N + NT / 64 - 1) / (NT / 64);
+  hipLaunchKernelGGL(linear_small_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, x, (const f16*)W, bias, y,
+                     M, N, K, silu_in);
+  ANIP_LAUNCH_CHECK("anip_linear_small");
+  return 0;
+}
+
+extern "C" int anip_add(const void* a, const void* b, void* out, int64_t n, void* stream) {
+  ANIP_REQUIRE(a && b && out && n > 0, "anip_add: bad arguments");
+  ANIP_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0, "anip_add: pointers must be 16-B aligned");
+  const int64_t nvec = n / 8;
+  hipLaunchKernelGGL(add_kernel, dim3(grid_for(nvec)), dim3(NT), 0, (hipStream_t)stream, (const f16*)a, (const f16*)b,
+                     (f16*)out, nvec, n);
+  ANIP_LAUNCH_CHECK("anip_add");
+  return 0;
+}
+
+extern "C" int anip_window_accumulate(const void* pred, float* acc, float* counter, const int* frames, int S, int Fw,
+                                      int L, int64_t HWC, void* stream) {
+  ANIP_REQUIRE(pred && acc && counter && frames, "anip_window_accumulate: null pointer");
+  ANIP_REQUIRE(S >= 1 && Fw >= 1 && Fw <= NT && L >= Fw, "anip_window_accumulate: bad sizes S=%d Fw=%d L=%d", S, Fw, L);
+  hipLaunchKernelGGL(window_accumulate_kernel, dim3(grid_for((int64_t)S * Fw * HWC)), dim3(NT), 0,
+                     (hipStream_t)stream, (const f16*)pred, acc, counter, frames, S, Fw, L, HWC);
+  ANIP_LAUNCH_CHECK("anip_window_accumulate");
+  return 0;
+}
+
+extern "C" int anip_cfg_ddim_step(const float* acc, const float* counter, float* latents, void* latents_f16, int S,
+                                  int L, int64_t HWC, float guidance, float sqrt_a, float sqrt_b, float sqrt_a_prev,
+                                  float sqrt_b_prev, void* stream) {
+  ANIP_REQUIRE(acc && counter && latents, "anip_cfg_ddim_step: null pointer");
+  ANIP_REQUIRE(S == 1 || S == 2, "anip_cfg_ddim_step: S must be 1 or 2");
+  hipLaunchKernelGGL(cfg_ddim_kernel, dim3(grid_for((int64_t)L * HWC)), dim3(NT), 0, (hipStream_t)stream, acc, counter,
+                     latents, (f16*)latents_f16, S, L, HWC, guidance, sqrt_a, sqrt_b, sqrt_a_prev, sqrt_b_prev);
+  ANIP_LAUNCH_CHECK("anip_cfg_ddim_step");
+  return 0;
+}
+
+extern "C" int anip_ncfhw_to_nhwc(const void* src, int src_f32, void* dst, int B, int C, int F, int64_t HW,
+                                  void* stream) {
+  ANIP_REQUIRE(src && dst && B > 0 && C > 0 && F > 0 && HW > 0, "anip_ncfhw_to_nhwc: bad arguments");
+  const int64_t total = (int64_t)B * C * F * HW;
+  if (src_f32)
+    hipLaunchKernelGGL(ncfhw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
+                       (const float*)src, (f16*)dst, B, C, F, HW);
+  else
+    hipLaunchKernelGGL(ncfhw_to_nhwc_kernel<f16>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
+                       (const f16*)src, (f16*)dst, B, C, F, HW);
+  ANIP_LAUNCH_CHECK("anip_ncfhw_to_nhwc");
+  return 0;
+}
+
+extern "C" int anip_nhwc_to_ncfhw(const void* src, void* dst, int dst_f32, int B, int C, int F, int64_t HW,
+                                  float scale, float shift, int clamp01, void* stream) {
+  ANIP_REQUIRE(src && dst && B > 0 && C > 0 && F > 0 && HW > 0, "anip_nhwc_to_ncfhw: bad arguments");
+  const int64_t total = (int64_t)B * C * F * HW;
+  if (dst_f32)
+    hipLaunchKernelGGL(nhwc_to_ncfhw_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
+                       (const f16*)src, (float*)dst, B, C, F, HW, scale, shift, clamp01);
+  else
+    hipLaunchKernelGGL(nhwc_to_ncfhw_kernel<f16>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
+                       (const f16*)src, (f16*)dst, B, C, F, HW, scale, shift, clamp01);
+  ANIP_LAUNCH_CHECK("anip_nhwc_to_ncfhw");
+  return 0;
+}

@@ -1,0 +1,311 @@
+// HBM-bound normalisation kernels for gfx950: per-frame GroupNorm (+SiLU, + fused channel concat),
+// LayerNorm (+ fused temporal positional encoding), fp32 row softmax.
+// Channels-last fp16 activations, fp32 statistics, 16-B vector loads/stores, deterministic
+// two-level reductions (no atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm pass 1: partial (sum, sumsq) per (image n, pixel chunk, group)
+// grid (nchunks, N); ws[((n * nchunks + chunk) * G + g) * 2 + {0,1}]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void gn_stats_kernel(const f16* __restrict__ x1, int C1, const f16* __restrict__ x2,
+                                                     int C2, int64_t HW, int G, int64_t ppc, float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // [rows_par][C][2]
+  const int C = C1 + C2;
+  const int CV = C >> 3;
+  const int tid = threadIdx.x;
+  const int n = blockIdx.y, chunk = blockIdx.x, nchunks = gridDim.x;
+  const int64_t p0 = (int64_t)chunk * ppc;
+  const int64_t p1 = min(HW, p0 + ppc);
+  const int rows_par = CV <= NT ? NT / CV : 1;
+
+  for (int cv0 = 0; cv0 < CV; cv0 += NT) {  // executes once unless C > 2048
+    int cv, r;
+    bool active;
+    if (CV <= NT) {
+      cv = tid % CV;
+      r = tid / CV;
+      active = r < rows_par;
+    } else {
+      cv = cv0 + tid;
+      r = 0;
+      active = cv < CV;
+    }
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.f;
+    if (active) {
+      const int c = cv << 3;
+      const bool second = c >= C1;
+      const f16* base = second ? x2 : x1;
+      const int Cs = second ? C2 : C1;
+      const int cc = second ? c - C1 : c;
+      for (int64_t p = p0 + r; p < p1; p += rows_par) {
+        U4H8 v;
+        v.u = *(const u32x4*)(base + ((int64_t)n * HW + p) * Cs + cc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float f = (float)v.e[e];
+          s[e] += f;
+          q[e] += f * f;
+        }
+      }
+      float* dst = sm + ((int64_t)r * C + c) * 2;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        dst[2 * e] = s[e];
+        dst[2 * e + 1] = q[e];
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < G) {
+    const int cpg = C / G;
+    float S = 0.f, Q = 0.f;
+    for (int r = 0; r < rows_par; ++r)
+      for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+        S += sm[((int64_t)r * C + c) * 2];
+        Q += sm[((int64_t)r * C + c) * 2 + 1];
+      }
+    float* o = ws + (((int64_t)n * nchunks + chunk) * G + tid) * 2;
+    o[0] = S;
+    o[1] = Q;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm pass 2: finalize stats, y = silu?((x - mean) * rstd * gamma + beta)
+// grid (apply_chunks, N)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void gn_apply_kernel(const f16* __restrict__ x1, int C1, const f16* __restrict__ x2,
+                                                     int C2, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, f16* __restrict__ y, int64_t HW,
+                                                     int G, float eps, int silu, const float* __restrict__ ws,
+                                                     int nchunks, int64_t ppc_apply) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // scale[C], shift[C], then mean[G], rstd[G]
+  const int C = C1 + C2;
+  const int CV = C >> 3;
+  const int tid = threadIdx.x;
+  const int n = blockIdx.y;
+  float* scale = sm;
+  float* shift = sm + C;
+  float* gmean = sm + 2 * C;
+  float* grstd = gmean + G;
+  const int cpg = C / G;
+  if (tid < G) {
+    float S = 0.f, Q = 0.f;
+    for (int ch = 0; ch < nchunks; ++ch) {
+      const float* o = ws + (((int64_t)n * nchunks + ch) * G + tid) * 2;
+      S += o[0];
+      Q += o[1];
+    }
+    const float cnt = (float)((double)HW * cpg);
+    const float mean = S / cnt;
+    const float var = fmaxf(Q / cnt - mean * mean, 0.f);
+    gmean[tid] = mean;
+    grstd[tid] = rsqrtf(var + eps);
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += NT) {
+    const int g = c / cpg;
+    const float sc = grstd[g] * gamma[c];
+    scale[c] = sc;
+    shift[c] = beta[c] - gmean[g] * sc;
+  }
+  __syncthreads();
+  const int64_t p0 = (int64_t)blockIdx.x * ppc_apply;
+  const int64_t p1 = min(HW, p0 + ppc_apply);
+  // walk the (pixel, channel-vector) space with stride NT without per-element divisions
+  const int npix = (int)(p1 - p0);
+  int cv = tid % CV, pp = tid / CV;
+  const int dcv = NT % CV, dpp = NT / CV;
+  for (; pp < npix; pp += dpp, cv += dcv) {
+    if (cv >= CV) {
+      cv -= CV;
+      if (++pp >= npix) break;
+    }
+    const int64_t p = p0 + pp;
+    const int c = cv << 3;
+    const bool second = c >= C1;
+    const f16* src = second ? x2 + ((int64_t)n * HW + p) * C2 + (c - C1) : x1 + ((int64_t)n * HW + p) * C1 + c;
+    U4H8 v, o;
+    v.u = *(const u32x4*)src;
+    const float4 s0 = *(const float4*)(scale + c), s1 = *(const float4*)(scale + c + 4);
+    const float4 h0 = *(const float4*)(shift + c), h1 = *(const float4*)(shift + c + 4);
+    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float f = (float)v.e[e] * sc[e] + sh[e];
+      if (silu) f = silu_f(f);
+      o.e[e] = (f16)f;
+    }
+    *(u32x4*)(y + ((int64_t)n * HW + p) * C + c) = o.u;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, two-pass in registers. C <= 2560, C % 8 == 0.
+// ---------------------------------------------------------------------------------------------
+constexpr int LN_MAXCH = 5;  // 5 chunks * 8 * 64 lanes = 2560 channels
+
+__global__ __launch_bounds__(NT) void layernorm_kernel(const f16* __restrict__ x, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, f16* __restrict__ y, int64_t M,
+                                                      int C, float eps, const float* __restrict__ pe,
+                                                      int64_t rows_per_frame, int F) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int CV = C >> 3;
+  const f16* xr = x + row * C;
+  float v[LN_MAXCH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAXCH; ++k) {
+    const int cv = lane + 64 * k;
+    if (cv < CV) {
+      U4H8 t;
+      t.u = *(const u32x4*)(xr + cv * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[k][e] = (float)t.e[e];
+        s += v[k][e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[k][e] = 0.f;
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAXCH; ++k) {
+    const int cv = lane + 64 * k;
+    if (cv < CV) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[k][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+  const float* per = nullptr;
+  if (pe != nullptr) per = pe + ((row / rows_per_frame) % F) * C;
+  f16* yr = y + row * C;
+#pragma unroll
+  for (int k = 0; k < LN_MAXCH; ++k) {
+    const int cv = lane + 64 * k;
+    if (cv < CV) {
+      const int c = cv * 8;
+      U4H8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float f = (v[k][e] - mean) * rstd * gamma[c + e] + beta[c + e];
+        if (per != nullptr) f += per[c + e];
+        o.e[e] = (f16)f;
+      }
+      *(u32x4*)(yr + c) = o.u;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// row softmax fp32 -> fp16, one block per row
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void softmax_rows_kernel(const float* __restrict__ s, f16* __restrict__ p, int cols) {
+  __shared__ float red[NT / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* sr = s + (int64_t)blockIdx.x * cols;
+  f16* pr = p + (int64_t)blockIdx.x * cols;
+  float mx = -INFINITY;
+  for (int c = tid; c < cols; c += NT) mx = fmaxf(mx, sr[c]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int c = tid; c < cols; c += NT) sum += __expf(sr[c] - mx);
+  sum = wave_sum(sum);
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  sum = red[0] + red[1] + red[2] + red[3];
+  const float inv = 1.0f / sum;
+  for (int c = tid; c < cols; c += NT) pr[c] = (f16)(__expf(sr[c] - mx) * inv);
+}
+
+static void gn_chunks(int N, int64_t HW, int* nchunks, int64_t* ppc) {
+  int64_t want = (1024 + N - 1) / N;          // aim at >= ~1024 workgroups
+  int64_t maxc = (HW + 63) / 64;              // at least 64 pixels per chunk
+  int64_t nc = want < maxc ? want : maxc;
+  if (nc < 1) nc = 1;
+  if (nc > 256) nc = 256;
+  *ppc = (HW + nc - 1) / nc;
+  *nchunks = (int)((HW + *ppc - 1) / *ppc);
+}
+
+}  // namespace
+
+extern "C" int64_t anip_groupnorm_ws_floats(int N, int64_t HW, int C, int G) {
+  int nchunks;
+  int64_t ppc;
+  gn_chunks(N, HW, &nchunks, &ppc);
+  (void)C;
+  return (int64_t)N * nchunks * G * 2;
+}
+
+extern "C" int anip_groupnorm(const void* x1, int C1, const void* x2, int C2, const float* gamma, const float* beta,
+                              void* y, int N, int64_t HW, int G, float eps, int silu, float* ws, void* stream) {
+  const int C = C1 + C2;
+  ANIP_REQUIRE(x1 && y && gamma && beta && ws, "anip_groupnorm: null pointer");
+  ANIP_REQUIRE(N > 0 && HW > 0 && G > 0 && G <= NT, "anip_groupnorm: bad sizes N=%d HW=%lld G=%d", N, (long long)HW, G);
+  ANIP_REQUIRE((C1 & 7) == 0 && (C2 & 7) == 0 && C % G == 0, "anip_groupnorm: C1=%d C2=%d must be multiples of 8, C %% G == 0", C1, C2);
+  ANIP_REQUIRE((C2 == 0) == (x2 == nullptr), "anip_groupnorm: x2/C2 mismatch");
+  ANIP_REQUIRE(C <= 8192, "anip_groupnorm: C=%d too large", C);
+  int nchunks;
+  int64_t ppc;
+  gn_chunks(N, HW, &nchunks, &ppc);
+  const int CV = C / 8;
+  const int rows_par = CV <= NT ? NT / CV : 1;
+  const size_t sm1 = (size_t)rows_par * C * 2 * sizeof(float);
+  ANIP_REQUIRE(sm1 <= 65536, "anip_groupnorm: stats LDS %zu too large", sm1);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, N), dim3(NT), sm1, (hipStream_t)stream, (const f16*)x1, C1,
+                     (const f16*)x2, C2, HW, G, ppc, ws);
+  ANIP_LAUNCH_CHECK("anip_groupnorm(stats)");
+  // apply: ~2048 pixels*C/8 vectors per block at least, >= 1024 blocks when possible
+  int64_t want = (2048 + N - 1) / N;
+  int64_t maxc = (HW + 15) / 16;
+  int64_t ac = want < maxc ? want : maxc;
+  if (ac < 1) ac = 1;
+  const int64_t ppa = (HW + ac - 1) / ac;
+  const int achunks = (int)((HW + ppa - 1) / ppa);
+  const size_t sm2 = (size_t)(2 * C + 2 * G) * sizeof(float);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(achunks, N), dim3(NT), sm2, (hipStream_t)stream, (const f16*)x1, C1,
+                     (const f16*)x2, C2, gamma, beta, (f16*)y, HW, G, eps, silu, (const float*)ws, nchunks, ppa);
+  ANIP_LAUNCH_CHECK("anip_groupnorm(apply)");
+  return 0;
+}
+
+extern "C" int anip_layernorm(const void* x, const float* gamma, const float* beta, void* y, int64_t M, int C,
+                              float eps, const float* pe, int64_t rows_per_frame, int F, void* stream) {
+  ANIP_REQUIRE(x && y && gamma && beta, "anip_layernorm: null pointer");
+  ANIP_REQUIRE(M > 0 && C > 0 && (C & 7) == 0 && C <= LN_MAXCH * 512, "anip_layernorm: bad C=%d (multiple of 8, <= %d)", C, LN_MAXCH * 512);
+  if (pe != nullptr) ANIP_REQUIRE(rows_per_frame > 0 && F > 0, "anip_layernorm: pe needs rows_per_frame, F");
+  const int64_t blocks = cdiv64(M, NT / 64);
+  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, (const f16*)x, gamma,
+                     beta, (f16*)y, M, C, eps, pe, rows_per_frame, F);
+  ANIP_LAUNCH_CHECK("anip_layernorm");
+  return 0;
+}
+
+extern "C" int anip_softmax_rows(const float* s, void* p, int64_t rows, int cols, void* stream) {
+  ANIP_REQUIRE(s && p && rows > 0 && cols > 0, "anip_softmax_rows: bad arguments");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(NT), 0, (hipStream_t)stream, s, (f16*)p, cols);
+  ANIP_LAUNCH_CHECK("anip_softmax_rows");
+  return 0;
+}

@@ -1,0 +1,276 @@
+"""Tensor-level wrappers over the C ABI (include/aniportrait_hip.h).
+
+PyTorch is used for device memory and streams only: every function here takes CUDA(HIP) tensors,
+passes raw pointers + sizes to libaniportrait_hip.so on torch's current stream and returns torch
+tensors that own the outputs.  Activations are channels-last fp16: (N, H, W, C) == (N*H*W, C).
+No fallbacks: a missing library or a non-GPU tensor raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+F16 = torch.float16
+F32 = torch.float32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _req(t, dtype, name):
+    if not t.is_cuda:
+        raise L.HipLibraryError(f"{name}: expected a GPU tensor (the hot path has no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return t
+
+
+def device_info():
+    lib = L.load()
+    buf = C.create_string_buffer(64)
+    ncu = C.c_int(0)
+    L.check(lib.anip_device_info(buf, 64, C.byref(ncu)), "anip_device_info")
+    return buf.value.decode(), ncu.value
+
+
+# ------------------------------------------------------------------------------------------------
+# weight packing (host side, once)
+# ------------------------------------------------------------------------------------------------
+
+def pack_conv3x3(w):
+    """torch conv weight [Cout, Cin, 3, 3] -> [Cout, 9*Cin] (tap-major, channels contiguous)."""
+    co, ci, kh, kw = w.shape
+    return w.permute(0, 2, 3, 1).reshape(co, kh * kw * ci).contiguous()
+
+
+def pack_geglu(w, b):
+    """FeedForward GEGLU projection [8C, C] (+bias [8C]) -> rows grouped per 64 output columns as
+    [64 x value | 64 x gate] so that one 128-wide GEMM tile holds matching value/gate columns."""
+    n2, k = w.shape
+    n = n2 // 2
+    assert n % 64 == 0, "GEGLU inner dim must be a multiple of 64"
+    wv, wg = w[:n].reshape(n // 64, 64, k), w[n:].reshape(n // 64, 64, k)
+    wp = torch.cat([wv, wg], dim=1).reshape(n2, k).contiguous()
+    bp = None
+    if b is not None:
+        bp = torch.cat([b[:n].reshape(n // 64, 64), b[n:].reshape(n // 64, 64)], dim=1).reshape(n2).contiguous()
+    return wp, bp
+
+
+# ------------------------------------------------------------------------------------------------
+# ops
+# ------------------------------------------------------------------------------------------------
+
+def groupnorm(x1, gamma, beta, groups, eps, silu, x2=None):
+    """x1 (N, HW, C1) [, x2 (N, HW, C2)] -> (N, HW, C1+C2): GroupNorm(+SiLU) of the channel concat."""
+    lib = L.load()
+    _req(x1, F16, "x1")
+    N, HW, C1 = x1.shape
+    C2 = 0
+    if x2 is not None:
+        _req(x2, F16, "x2")
+        C2 = x2.shape[-1]
+    Ctot = C1 + C2
+    y = torch.empty((N, HW, Ctot), dtype=F16, device=x1.device)
+    ws = torch.empty((lib.anip_groupnorm_ws_floats(N, HW, Ctot, groups),), dtype=F32, device=x1.device)
+    L.check(lib.anip_groupnorm(_p(x1), C1, _p(x2), C2, _p(_req(gamma, F32, "gamma")), _p(_req(beta, F32, "beta")),
+                               _p(y), N, HW, groups, float(eps), int(bool(silu)), _p(ws), _stream()),
+            "anip_groupnorm")
+    return y
+
+
+def layernorm(x, gamma, beta, eps=1e-5, pe=None, rows_per_frame=0, frames=0):
+    lib = L.load()
+    _req(x, F16, "x")
+    M, Cc = x.shape
+    y = torch.empty_like(x)
+    L.check(lib.anip_layernorm(_p(x), _p(_req(gamma, F32, "gamma")), _p(_req(beta, F32, "beta")), _p(y), M, Cc,
+                               float(eps), _p(pe), int(rows_per_frame), int(frames), _stream()), "anip_layernorm")
+    return y
+
+
+def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None, act=0, out_f32=False,
+         alpha=1.0, out=None, conv=None, batch=1):
+    """out = epilogue(alpha * A @ W^T).
+
+    A (M, K) fp16 [+ A2 (M, K2): K split over two sources]; W (N, K) fp16; bias (N,) fp32;
+    rowbias (M/rows_per_group, N) fp32; residual (M, N) fp16; act=1 -> GEGLU (W packed by pack_geglu).
+    conv: dict(Nimg, Hin, Win, Cin, Hout, Wout, stride, pad, upsample) -> A is the NHWC image batch.
+    batch > 1: A (B, M, K), W (B, N, K) -> out (B, M, N).
+    """
+    lib = L.load()
+    p = L.GemmParams()
+    _req(A, F16, "A")
+    _req(W, F16, "W")
+    if batch > 1:
+        Bn, M, K = A.shape
+        N = W.shape[1]
+        p.batch, p.strideA, p.strideW, p.strideO = batch, M * K, N * K, M * N
+        p.lda = K
+    elif conv is not None:
+        M = conv["Nimg"] * conv["Hout"] * conv["Wout"]
+        K = 9 * conv["Cin"]
+        N = W.shape[0]
+        p.conv = 1
+        for k in ("Nimg", "Hin", "Win", "Cin", "Hout", "Wout", "stride", "pad"):
+            setattr(p, k, int(conv[k]))
+        p.upsample = int(bool(conv.get("upsample", False)))
+        p.batch = 1
+    else:
+        M, K1 = A.shape
+        K = K1
+        N = W.shape[0]
+        p.lda = K1
+        p.batch = 1
+        if A2 is not None:
+            _req(A2, F16, "A2")
+            p.A2, p.lda2, p.K1 = _p(A2), A2.shape[1], K1
+            K = K1 + A2.shape[1]
+    assert W.shape[-1] == K, f"W has K={W.shape[-1]}, expected {K}"
+    n_out = N // 2 if act == 1 else N
+    if out is None:
+        shape = (batch, M, n_out) if batch > 1 else (M, n_out)
+        out = torch.empty(shape, dtype=F32 if out_f32 else F16, device=A.device)
+    p.A, p.W, p.ldw = _p(A), _p(W), K
+    p.out, p.ldo, p.out_f32 = _p(out), n_out, int(out_f32)
+    p.M, p.N, p.K = M, N, K
+    p.alpha = float(alpha)
+    p.bias = _p(bias)
+    if rowbias is not None:
+        p.rowbias, p.rows_per_group, p.ld_rowbias = _p(rowbias), int(rows_per_group), rowbias.shape[-1]
+    if residual is not None:
+        _req(residual, F16, "residual")
+        p.residual, p.ldr = _p(residual), n_out
+    p.act = int(act)
+    L.check(lib.anip_gemm(C.byref(p), _stream()), "anip_gemm")
+    return out
+
+
+def conv3x3(x, Wp, bias, stride=1, pad=1, upsample=False, pad_hi=None, rowbias=None, rows_per_group=0,
+            residual=None, out_f32=False):
+    """x (N, H, W, Cin) fp16, Wp (Cout, 9*Cin) packed by pack_conv3x3 -> (N, Ho, Wo, Cout).
+    pad = low-side padding; pad_hi (default = pad) = high-side padding (VAE encoder uses 0/1)."""
+    N, H, Wd, Cin = x.shape
+    if pad_hi is None:
+        pad_hi = pad
+    He, We = (2 * H, 2 * Wd) if upsample else (H, Wd)
+    Ho = (He + pad + pad_hi - 3) // stride + 1
+    Wo = (We + pad + pad_hi - 3) // stride + 1
+    conv = dict(Nimg=N, Hin=H, Win=Wd, Cin=Cin, Hout=Ho, Wout=Wo, stride=stride, pad=pad, upsample=upsample)
+    res2 = residual.reshape(-1, Wp.shape[0]) if residual is not None else None
+    out = gemm(x, Wp, bias, rowbias=rowbias, rows_per_group=rows_per_group, residual=res2, conv=conv,
+               out_f32=out_f32)
+    return out.reshape(N, Ho, Wo, Wp.shape[0])
+
+
+def conv_small(x, w, bias, ksize, residual=None):
+    """x (N, H, W, Cin<=8) fp16, w (Cout, k, k, Cin) fp16 -> (N, H, W, Cout) (stride 1, same padding)."""
+    lib = L.load()
+    _req(x, F16, "x")
+    _req(w, F16, "w")
+    N, H, Wd, Cin = x.shape
+    Cout = w.shape[0]
+    y = torch.empty((N, H, Wd, Cout), dtype=F16, device=x.device)
+    L.check(lib.anip_conv_small(_p(x), _p(w), _p(bias), _p(residual), _p(y), N, H, Wd, Cin, Cout, ksize, _stream()),
+            "anip_conv_small")
+    return y
+
+
+def ref_attention(q, ldq, k, ldk, vt, ldvt, n_frames, T, heads, d, kref=None, ldkr=0, vtref=None, ldvtr=0,
+                  ref_index=None, scale=None):
+    """see anip_ref_attention; returns (n_frames*T, heads*d) fp16."""
+    lib = L.load()
+    out = torch.empty((n_frames * T, heads * d), dtype=F16, device=q.device)
+    if scale is None:
+        scale = d ** -0.5
+    L.check(lib.anip_ref_attention(_p(q), ldq, _p(k), ldk, _p(vt), ldvt, _p(kref), ldkr, _p(vtref), ldvtr,
+                                   _p(ref_index), _p(out), heads * d, n_frames, T, heads, d, float(scale), _stream()),
+            "anip_ref_attention")
+    return out
+
+
+def temporal_attention(qkv, B, F, T, heads, d, scale=None):
+    lib = L.load()
+    _req(qkv, F16, "qkv")
+    out = torch.empty((B * F * T, heads * d), dtype=F16, device=qkv.device)
+    if scale is None:
+        scale = d ** -0.5
+    L.check(lib.anip_temporal_attention(_p(qkv), _p(out), B, F, T, heads, d, float(scale), _stream()),
+            "anip_temporal_attention")
+    return out
+
+
+def softmax_rows(s):
+    lib = L.load()
+    _req(s, F32, "s")
+    rows = s.numel() // s.shape[-1]
+    p = torch.empty(s.shape, dtype=F16, device=s.device)
+    L.check(lib.anip_softmax_rows(_p(s), _p(p), rows, s.shape[-1], _stream()), "anip_softmax_rows")
+    return p
+
+
+def linear_small(x, W, bias=None, silu_in=False):
+    """x (M<=16, K) fp32, W (N, K) fp16 -> (M, N) fp32."""
+    lib = L.load()
+    _req(x, F32, "x")
+    _req(W, F16, "W")
+    M, K = x.shape
+    N = W.shape[0]
+    y = torch.empty((M, N), dtype=F32, device=x.device)
+    L.check(lib.anip_linear_small(_p(x), _p(W), _p(bias), _p(y), M, N, K, int(bool(silu_in)), _stream()),
+            "anip_linear_small")
+    return y
+
+
+def add(a, b):
+    lib = L.load()
+    _req(a, F16, "a")
+    _req(b, F16, "b")
+    out = torch.empty_like(a)
+    L.check(lib.anip_add(_p(a), _p(b), _p(out), a.numel(), _stream()), "anip_add")
+    return out
+
+
+def window_accumulate(pred, acc, counter, frames, S, Fw, L_, HWC):
+    lib = L.load()
+    L.check(lib.anip_window_accumulate(_p(pred), _p(acc), _p(counter), _p(frames), S, Fw, L_, HWC, _stream()),
+            "anip_window_accumulate")
+
+
+def cfg_ddim_step(acc, counter, latents, latents_f16, S, L_, HWC, guidance, sa, sb, sap, sbp):
+    lib = L.load()
+    L.check(lib.anip_cfg_ddim_step(_p(acc), _p(counter), _p(latents), _p(latents_f16), S, L_, HWC, float(guidance),
+                                   float(sa), float(sb), float(sap), float(sbp), _stream()), "anip_cfg_ddim_step")
+
+
+def ncfhw_to_nhwc(src):
+    """(B, C, F, H, W) fp32/fp16 -> (B*F, H, W, C) fp16."""
+    lib = L.load()
+    if not src.is_cuda:
+        raise L.HipLibraryError("ncfhw_to_nhwc: expected a GPU tensor")
+    src = src.contiguous()
+    B, Cc, Fr, H, Wd = src.shape
+    dst = torch.empty((B * Fr, H, Wd, Cc), dtype=F16, device=src.device)
+    L.check(lib.anip_ncfhw_to_nhwc(_p(src), int(src.dtype == F32), _p(dst), B, Cc, Fr, H * Wd, _stream()),
+            "anip_ncfhw_to_nhwc")
+    return dst
+
+
+def nhwc_to_ncfhw(src, B, out_f32=False, scale=1.0, shift=0.0, clamp01=False):
+    """(B*F, H, W, C) fp16 -> (B, C, F, H, W)."""
+    lib = L.load()
+    _req(src, F16, "src")
+    BF, H, Wd, Cc = src.shape
+    Fr = BF // B
+    dst = torch.empty((B, Cc, Fr, H, Wd), dtype=F32 if out_f32 else F16, device=src.device)
+    L.check(lib.anip_nhwc_to_ncfhw(_p(src), _p(dst), int(out_f32), B, Cc, Fr, H * Wd, float(scale), float(shift),
+                                   int(bool(clamp01)), _stream()), "anip_nhwc_to_ncfhw")
+    return dst

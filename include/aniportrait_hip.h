@@ -1,0 +1,141 @@
+/*
+ * aniportrait_hip.h — C ABI of libaniportrait_hip.so (gfx950 / MI355X only).
+ *
+ * The reference (Zejun-Yang/AniPortrait @ 2024_08_07) has NO native/FFI layer: its hot path reaches
+ * the device through stock torch/diffusers ops.  This header is therefore the boundary a maintainer
+ * would bind (ctypes) to replace exactly those ops; every entry point names the
+ * reference call site(s) whose arithmetic it replaces.
+ *
+ * Conventions
+ *  - plain pointers + sizes, no torch types; all pointers are DEVICE pointers owned by the caller
+ *    (PyTorch-ROCm allocations); no allocation, no ownership transfer, no exceptions.
+ *  - activations are channels-last: an image batch (N,H,W,C) == a token matrix (N*H*W, C), fp16.
+ *    1-D parameters (norm gamma/beta, biases) are fp32; weight matrices are fp16, row-major [out][in]
+ *    (conv weights [Cout][ky][kx][Cin]).
+ *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream).
+ *  - return 0 on success, <0 on error; anip_last_error() returns a thread-local message.
+ *  - all accumulation is fp32; outputs are rounded to fp16 once.
+ */
+#ifndef ANIPORTRAIT_HIP_H
+#define ANIPORTRAIT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ANIP_ABI_VERSION 1
+
+int anip_version(void);
+const char* anip_last_error(void);
+/* device name / gfx arch / CU count of the current device into caller buffers; 0 on success */
+int anip_device_info(char* arch, int arch_len, int* num_cu);
+
+/* ---- GroupNorm (+SiLU), per frame ---------------------------------------------------------------
+ * replaces InflatedGroupNorm / nn.GroupNorm (+ F.silu):  src/models/resnet.py:21-29,221-222,232-238,
+ * src/models/transformer_3d.py:124, src/models/motion_module.py:156, src/models/unet_3d.py:573-574,
+ * diffusers ResnetBlock2D / AutoencoderKL norms.
+ * x = concat_C(x1 [N,HW,C1], x2 [N,HW,C2]) (x2 may be NULL, C2 = 0: fuses the skip-concat of
+ * src/models/unet_3d_blocks.py:697,826 into the norm).  y [N,HW,C1+C2] fp16.
+ * ws: fp32 workspace of anip_groupnorm_ws_floats(N,HW,C,G) elements. */
+int64_t anip_groupnorm_ws_floats(int N, int64_t HW, int C, int G);
+int anip_groupnorm(const void* x1, int C1, const void* x2, int C2, const float* gamma, const float* beta,
+                   void* y, int N, int64_t HW, int G, float eps, int silu, float* ws, void* stream);
+
+/* ---- LayerNorm over the last dim --------------------------------------------------------------
+ * replaces nn.LayerNorm: src/models/attention.py:331-335,352-362, src/models/motion_module.py:228,234.
+ * Optional fused temporal positional-encoding add (src/models/motion_module.py:262-277,365-366):
+ * y[m] = LN(x[m]) + pe[(m / rows_per_frame) % F]  (pe fp32 [F][C], NULL to disable). */
+int anip_layernorm(const void* x, const float* gamma, const float* beta, void* y, int64_t M, int C, float eps,
+                   const float* pe, int64_t rows_per_frame, int F, void* stream);
+
+/* ---- GEMM / implicit-GEMM 3x3 convolution on MFMA -----------------------------------------------
+ * out[M,N] = epilogue( alpha * A[M,K] @ W[N,K]^T ), fp16 in, fp32 accumulate.
+ * replaces every nn.Linear / 1x1 / 3x3 Conv2d on the path: diffusers Attention to_q/k/v/out and
+ * FeedForward (src/models/attention.py:323-361, src/models/motion_module.py:122,144,233),
+ * InflatedConv3d (src/models/resnet.py:10-18,166-168,195-197,214-216), Upsample3D/Downsample3D convs
+ * (src/models/resnet.py:52,72-74,107-109), Transformer3D proj_in/out (src/models/transformer_3d.py:64,93),
+ * AutoencoderKL convs. */
+typedef struct anip_gemm_params {
+  /* A operand: plain mode = row-major [M][K] possibly split over two sources along K
+   * (k < K1 -> A, else A2; fuses torch.cat([h, skip], dim=1) into the 1x1 shortcut conv). */
+  const void* A;   int64_t lda;
+  const void* A2;  int64_t lda2;  int K1;
+  const void* W;   int64_t ldw;          /* [N][K] fp16 */
+  void* out;       int64_t ldo;          /* [M][N] (GEGLU: [M][N/2]) */
+  int out_f32;                           /* 0: fp16 out, 1: fp32 out */
+  int M, N, K;
+  float alpha;
+  const float* bias;                     /* [N] or NULL */
+  const float* rowbias; int64_t rows_per_group; int64_t ld_rowbias; /* + rowbias[m / rows_per_group][n]:
+                                            time-embedding add (resnet.py:226-230) and the collapsed
+                                            length-1 CLIP cross-attention (mutual_self_attention.py:191-205) */
+  const void* residual; int64_t ldr;     /* fp16 [M][N] added last, or NULL */
+  int act;                               /* 0 none; 1 GEGLU: W/bias rows packed per 128-row tile as
+                                            [64 x h | 64 x gate], out = h * gelu_erf(gate) */
+  int batch; int64_t strideA, strideW, strideO; /* batched GEMM over blockIdx.y (elements) */
+  /* implicit 3x3 convolution (conv != 0): A is an NHWC image batch, M = Nimg*Hout*Wout, K = 9*Cin,
+   * W = [Cout][3][3][Cin].  upsample=1 fuses nearest-2x (resnet.py:72-74) into the gather. */
+  int conv; int Nimg, Hin, Win, Cin, Hout, Wout, stride, pad, upsample;
+} anip_gemm_params;
+int anip_gemm(const anip_gemm_params* p, void* stream);
+
+/* ---- small-channel direct convolution (Cin or Cout not MFMA-shaped) -----------------------------
+ * conv_in 4->C (src/models/unet_3d.py:90-92,484), AutoencoderKL post_quant_conv / decoder.conv_in.
+ * x [N,H,W,Cin] fp16, w [Cout][k][k][Cin] fp16, bias fp32, optional residual [N,H,W,Cout] fp16
+ * (pose feature add, unet_3d.py:485-486), y fp16.  ksize 1 or 3, stride 1, pad ksize/2. */
+int anip_conv_small(const void* x, const void* w, const float* bias, const void* residual, void* y,
+                    int N, int H, int W, int Cin, int Cout, int ksize, void* stream);
+
+/* ---- reference attention (spatial) ---------------------------------------------------------------
+ * replaces attn1 of the hacked TemporalBasicTransformerBlock in read mode
+ * (src/models/mutual_self_attention.py:147-186 -> diffusers AttnProcessor2_0 -> SDPA) and plain
+ * self-attention of the ReferenceNet (write mode, :137-146).
+ * For frame n, head h: O = softmax(Q K^T / sqrt(d)) V with keys = [self tokens of frame n]
+ * ++ [reference tokens of sample ref_index[n]] (ref_index[n] < 0: self only, the CFG-unconditional
+ * frames).  q,k: [Nf*T][ld] fp16 with head h at column h*d; vt: V transposed [heads*d][ldvt] with
+ * token (n*T + t) at column n*T+t; kref [Nref*T][ldkr], vtref [heads*d][ldvtr]; out [Nf*T][ldo]. */
+int anip_ref_attention(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
+                       const void* kref, int64_t ldkr, const void* vtref, int64_t ldvtr,
+                       const int* ref_index, void* out, int64_t ldo,
+                       int Nf, int T, int heads, int d, float scale, void* stream);
+
+/* ---- temporal self-attention ------------------------------------------------------------------
+ * replaces VersatileAttention (src/models/motion_module.py:351-388): for every (b, pixel t, head):
+ * attention over the F frames.  qkv [(b F) T][3C] fp16 (q|k|v), out [(b F) T][C]. */
+int anip_temporal_attention(const void* qkv, void* out, int B, int F, int T, int heads, int d, float scale,
+                            void* stream);
+
+/* ---- row softmax fp32 -> fp16 (VAE mid-block attention, diffusers Attention upcast_softmax) ---- */
+int anip_softmax_rows(const float* s, void* p, int64_t rows, int cols, void* stream);
+
+/* ---- tiny dense layers (M <= 16 rows): time embedding MLP, time_emb_proj, collapsed attn2 -------
+ * y[m][n] = sum_k f(x[m][k]) * W[n][k] + bias[n], f = SiLU if silu_in.  x,y fp32; W fp16.
+ * (src/models/unet_3d.py:463-469, src/models/resnet.py:226-227) */
+int anip_linear_small(const float* x, const void* W, const float* bias, float* y, int M, int N, int K,
+                      int silu_in, void* stream);
+
+/* ---- elementwise -------------------------------------------------------------------------------- */
+/* out = a + b (fp16), pose-feature adds (src/models/unet_3d.py:508-510) */
+int anip_add(const void* a, const void* b, void* out, int64_t n, void* stream);
+/* acc[s][frames[j]] += pred[s][j], counter[frames[j]] += 1 for one context window
+ * (src/pipelines/pipeline_pose2vid_long.py:546-548).  pred fp16 [S][Fw][HWC], acc fp32 [S][L][HWC]. */
+int anip_window_accumulate(const void* pred, float* acc, float* counter, const int* frames, int S, int Fw, int L,
+                           int64_t HWC, void* stream);
+/* CFG combine + DDIM v-prediction update (pipeline_pose2vid_long.py:551-559 + DDIMScheduler.step):
+ * eps = acc/counter ; v = u + g (c - u) (S == 2) or acc (S == 1, not divided: reference quirk) ;
+ * x0 = sa*x - sb*v ; e = sa*v + sb*x ; x <- sap*x0 + sbp*e.  latents fp32 [L][HWC] in place;
+ * also writes fp16 copy for the next UNet call. */
+int anip_cfg_ddim_step(const float* acc, const float* counter, float* latents, void* latents_f16, int S, int L,
+                       int64_t HWC, float guidance, float sqrt_a, float sqrt_b, float sqrt_a_prev,
+                       float sqrt_b_prev, void* stream);
+/* layout/dtype conversion between (B,C,F,H,W) [fp32 or fp16] and channels-last frames (B*F,H,W,C) fp16 */
+int anip_ncfhw_to_nhwc(const void* src, int src_f32, void* dst, int B, int C, int F, int64_t HW, void* stream);
+int anip_nhwc_to_ncfhw(const void* src, void* dst, int dst_f32, int B, int C, int F, int64_t HW, float scale,
+                       float shift, int clamp01, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,347 @@
+"""Kernel-level parity: every C-ABI compute entry point against a plain PyTorch fp32 reference of
+the same op, on identical fp16-representable inputs.  Tolerance: the outputs are fp16 (one rounding
+of an fp32-accumulated result), so |hip - ref| <= 2e-3 * |ref| + 2e-3 * rms(ref) element-wise
+(fp16 ulp = 2^-11 ~ 4.9e-4 relative)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    from aniportrait_amd import hipops
+    return hipops
+
+
+def rnd(*shape, scale=1.0, seed=0, shift=0.0):
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed + sum(shape))
+    return (torch.randn(shape, generator=g) * scale + shift).half()
+
+
+def close(out, ref, what, rtol=2e-3, arms=2e-3):
+    out = out.float().cpu()
+    ref = ref.float().cpu()
+    assert out.shape == ref.shape, f"{what}: shape {tuple(out.shape)} vs {tuple(ref.shape)}"
+    assert torch.isfinite(out).all(), f"{what}: non-finite output"
+    rms = ref.pow(2).mean().sqrt().item()
+    err = (out - ref).abs()
+    tol = rtol * ref.abs() + arms * rms + 1e-6
+    bad = (err > tol)
+    worst = (err / tol).max().item()
+    print(f"[{what}] max_abs_err={err.max().item():.3e} rms_ref={rms:.3e} worst_err/tol={worst:.2f}")
+    assert not bad.any(), (f"{what}: {int(bad.sum())}/{bad.numel()} elements out of tolerance, "
+                           f"max_abs_err={err.max().item():.3e}, rms_ref={rms:.3e}, worst err/tol={worst:.1f}, "
+                           f"first bad idx={bad.nonzero()[0].tolist()}")
+
+
+def test_library_loads_on_gpu_box():
+    arch, ncu = _ops().device_info()
+    print("device:", arch, ncu)
+    assert arch.startswith("gfx950"), arch
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 72, 136), (1000, 320, 320), (130, 4, 64), (64, 3, 128),
+                                   (2048, 1280, 2560), (77, 640, 1280)])
+def test_gemm_plain(M, N, K):
+    ops = _ops()
+    A = rnd(M, K, seed=1).to(DEV)
+    W = rnd(N, K, seed=2, scale=K ** -0.5).to(DEV)
+    bias = rnd(N, seed=3).float().to(DEV)
+    out = ops.gemm(A, W, bias)
+    ref = A.float() @ W.float().t() + bias
+    close(out, ref, f"gemm {M}x{N}x{K}")
+
+
+def test_gemm_asymmetric_identity():
+    """A = I with an asymmetric W catches operand/transpose mix-ups in the MFMA fragment layout."""
+    ops = _ops()
+    K = 64
+    A = torch.eye(K).half().to(DEV)
+    W = (torch.arange(128 * K).reshape(128, K).float() / 1000.0).half().to(DEV)  # W[n][k] = (n*K + k)/1000
+    out = ops.gemm(A, W)
+    close(out, W.float().t(), "gemm identity")
+
+
+def test_gemm_epilogues():
+    ops = _ops()
+    M, N, K = 300, 192, 192
+    A = rnd(M, K, seed=4).to(DEV)
+    W = rnd(N, K, seed=5, scale=K ** -0.5).to(DEV)
+    bias = rnd(N, seed=6).float().to(DEV)
+    rowbias = rnd(6, N, seed=7).float().to(DEV)
+    res = rnd(M, N, seed=8).to(DEV)
+    base = A.float() @ W.float().t()
+    out = ops.gemm(A, W, bias, rowbias=rowbias, rows_per_group=50, residual=res)
+    ref = base + bias + rowbias.repeat_interleave(50, dim=0) + res.float()
+    close(out, ref, "gemm bias+rowbias+residual")
+    out = ops.gemm(A, W, None, alpha=0.25, out_f32=True)
+    assert out.dtype == torch.float32
+    close(out, 0.25 * base, "gemm alpha fp32-out", rtol=1e-4, arms=1e-4)
+
+
+def test_gemm_two_source():
+    ops = _ops()
+    M, K1, K2, N = 333, 128, 64, 136
+    A1 = rnd(M, K1, seed=9).to(DEV)
+    A2 = rnd(M, K2, seed=10).to(DEV)
+    W = rnd(N, K1 + K2, seed=11, scale=0.1).to(DEV)
+    out = ops.gemm(A1, W, None, A2=A2)
+    ref = torch.cat([A1, A2], 1).float() @ W.float().t()
+    close(out, ref, "gemm two-source K")
+
+
+@pytest.mark.parametrize("C", [64, 320])
+def test_gemm_geglu(C):
+    ops = _ops()
+    M = 260
+    A = rnd(M, C, seed=12).to(DEV)
+    W = rnd(8 * C, C, seed=13, scale=C ** -0.5)
+    b = rnd(8 * C, seed=14).float()
+    Wp, bp = ops.pack_geglu(W, b)
+    out = ops.gemm(A, Wp.to(DEV), bp.to(DEV), act=1)
+    proj = A.float().cpu() @ W.float().t() + b
+    h, g = proj.chunk(2, dim=-1)
+    close(out, h * F.gelu(g), f"gemm GEGLU C={C}")
+
+
+def test_gemm_batched():
+    ops = _ops()
+    B, M, N, K = 3, 70, 96, 64
+    A = rnd(B, M, K, seed=15).to(DEV)
+    W = rnd(B, N, K, seed=16, scale=0.2).to(DEV)
+    out = ops.gemm(A, W, None, batch=B, out_f32=True)
+    close(out, torch.bmm(A.float(), W.float().transpose(1, 2)), "gemm batched", rtol=1e-4, arms=1e-4)
+
+
+# ------------------------------------------------------------------------------------------------
+# 3x3 conv (implicit GEMM)
+# ------------------------------------------------------------------------------------------------
+def _conv_ref(x, w, b, stride, pad, pad_hi, upsample):
+    xr = x.float().permute(0, 3, 1, 2)
+    if upsample:
+        xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
+    xr = F.pad(xr, (pad, pad_hi, pad, pad_hi))
+    y = F.conv2d(xr, w.float(), b, stride=stride)
+    return y.permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,stride,pad,pad_hi,up", [
+    (2, 9, 7, 64, 72, 1, 1, 1, False),
+    (2, 8, 8, 64, 64, 2, 1, 1, False),
+    (1, 5, 6, 128, 64, 1, 1, 1, True),
+    (2, 8, 6, 64, 128, 2, 0, 1, False),
+    (2, 16, 16, 128, 320, 1, 1, 1, False),
+    (1, 4, 4, 1280, 640, 1, 1, 1, False),
+    (3, 2, 2, 64, 64, 1, 1, 1, False),
+])
+def test_conv3x3(N, H, W, Cin, Cout, stride, pad, pad_hi, up):
+    ops = _ops()
+    x = rnd(N, H, W, Cin, seed=20).to(DEV)
+    w = rnd(Cout, Cin, 3, 3, seed=21, scale=(9 * Cin) ** -0.5)
+    b = rnd(Cout, seed=22).float()
+    out = ops.conv3x3(x, ops.pack_conv3x3(w).to(DEV), b.to(DEV), stride=stride, pad=pad, upsample=up, pad_hi=pad_hi)
+    ref = _conv_ref(x.cpu(), w, b, stride, pad, pad_hi, up)
+    close(out, ref, f"conv3x3 {N}x{H}x{W} {Cin}->{Cout} s{stride} p{pad}/{pad_hi} up={up}")
+
+
+def test_conv3x3_rowbias_residual():
+    ops = _ops()
+    N, H, W, Cin, Cout = 4, 6, 6, 64, 128
+    x = rnd(N, H, W, Cin, seed=23).to(DEV)
+    w = rnd(Cout, Cin, 3, 3, seed=24, scale=(9 * Cin) ** -0.5)
+    b = rnd(Cout, seed=25).float()
+    temb = rnd(2, Cout, seed=26).float()      # 2 samples x 2 frames each
+    res = rnd(N, H, W, Cout, seed=27).to(DEV)
+    out = ops.conv3x3(x, ops.pack_conv3x3(w).to(DEV), b.to(DEV), rowbias=temb.to(DEV), rows_per_group=2 * H * W,
+                      residual=res)
+    ref = _conv_ref(x.cpu(), w, b, 1, 1, 1, False) + temb.repeat_interleave(2, 0)[:, None, None, :] + res.float().cpu()
+    close(out, ref, "conv3x3 + temb rowbias + residual")
+
+
+@pytest.mark.parametrize("Cin,Cout,ks", [(4, 320, 3), (4, 4, 1), (4, 512, 3), (3, 64, 3)])
+def test_conv_small(Cin, Cout, ks):
+    ops = _ops()
+    N, H, W = 2, 9, 11
+    x = rnd(N, H, W, Cin, seed=30).to(DEV)
+    w = rnd(Cout, Cin, ks, ks, seed=31, scale=0.3)
+    b = rnd(Cout, seed=32).float()
+    res = rnd(N, H, W, Cout, seed=33).to(DEV)
+    wp = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    out = ops.conv_small(x, wp, b.to(DEV), ks, residual=res)
+    ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.float(), b, padding=ks // 2).permute(0, 2, 3, 1) + res.float().cpu()
+    close(out, ref, f"conv_small {Cin}->{Cout} k{ks}")
+
+
+# ------------------------------------------------------------------------------------------------
+# norms
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,HW,C1,C2,silu,eps,shift", [
+    (3, 50, 64, 0, True, 1e-5, 0.0), (2, 256, 320, 0, True, 1e-5, 0.0), (2, 64, 128, 64, True, 1e-5, 0.0),
+    (2, 4, 1280, 1280, True, 1e-5, 0.0), (1, 4096, 128, 0, False, 1e-6, 3.0), (2, 100, 640, 320, False, 1e-6, 0.0),
+    (1, 70000, 64, 0, True, 1e-6, 0.5),
+])
+def test_groupnorm(N, HW, C1, C2, silu, eps, shift):
+    ops = _ops()
+    x1 = rnd(N, HW, C1, seed=40, shift=shift).to(DEV)
+    x2 = rnd(N, HW, C2, seed=41, scale=2.0).to(DEV) if C2 else None
+    Ct = C1 + C2
+    gamma = (1 + 0.1 * rnd(Ct, seed=42).float()).to(DEV)
+    beta = (0.1 * rnd(Ct, seed=43).float()).to(DEV)
+    out = ops.groupnorm(x1, gamma, beta, 32, eps, silu, x2=x2)
+    x = torch.cat([x1, x2], -1) if C2 else x1
+    ref = F.group_norm(x.float().permute(0, 2, 1), 32, gamma, beta, eps).permute(0, 2, 1)
+    if silu:
+        ref = F.silu(ref)
+    close(out, ref, f"groupnorm N{N} HW{HW} C{C1}+{C2}")
+
+
+@pytest.mark.parametrize("M,C,pe", [(77, 320, False), (130, 1280, False), (2 * 4 * 10, 64, True), (9, 2560, False)])
+def test_layernorm(M, C, pe):
+    ops = _ops()
+    x = rnd(M, C, seed=50, shift=0.3).to(DEV)
+    gamma = (1 + 0.1 * rnd(C, seed=51).float()).to(DEV)
+    beta = (0.1 * rnd(C, seed=52).float()).to(DEV)
+    ref = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5)
+    if pe:
+        Fr, T = 4, 10
+        table = rnd(Fr, C, seed=53).float().to(DEV)
+        out = ops.layernorm(x, gamma, beta, 1e-5, pe=table, rows_per_frame=T, frames=Fr)
+        idx = (torch.arange(M, device=DEV) // T) % Fr
+        ref = ref + table[idx]
+    else:
+        out = ops.layernorm(x, gamma, beta, 1e-5)
+    close(out, ref, f"layernorm {M}x{C} pe={pe}")
+
+
+def test_softmax_rows():
+    ops = _ops()
+    s = (rnd(37, 4096, seed=60, scale=3.0).float()).to(DEV)
+    close(ops.softmax_rows(s), torch.softmax(s, -1), "softmax rows 4096", rtol=2e-3, arms=1e-2)
+    s = (rnd(5, 100, seed=61, scale=10.0).float()).to(DEV)
+    close(ops.softmax_rows(s), torch.softmax(s, -1), "softmax rows 100", rtol=2e-3, arms=1e-2)
+
+
+# ------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------
+def _attn_ref(q, k, v, scale):
+    s = torch.einsum("hqd,hkd->hqk", q, k) * scale
+    return torch.einsum("hqk,hkd->hqd", torch.softmax(s, -1), v)
+
+
+@pytest.mark.parametrize("d", [8, 16, 32, 40, 64, 80, 160])
+@pytest.mark.parametrize("T", [4, 16, 100, 256])
+def test_ref_attention(d, T):
+    ops = _ops()
+    heads, Nf, Nref = 2, 3, 2
+    Cc = heads * d
+    qk = rnd(Nf * T, 2 * Cc, seed=70).to(DEV)                  # [q | k]
+    v = rnd(Nf * T, Cc, seed=71).to(DEV)
+    kref = rnd(Nref * T, Cc, seed=72).to(DEV)
+    vref = rnd(Nref * T, Cc, seed=73).to(DEV)
+    ref_index = torch.tensor([-1, 1, 0], dtype=torch.int32, device=DEV)
+    vt = v.t().contiguous()
+    vtref = vref.t().contiguous()
+    out = ops.ref_attention(qk, 2 * Cc, qk[:, Cc:], 2 * Cc, vt, Nf * T, Nf, T, heads, d, kref=kref, ldkr=Cc,
+                            vtref=vtref, ldvtr=Nref * T, ref_index=ref_index)
+    refs = []
+    for n in range(Nf):
+        q_ = qk[n * T:(n + 1) * T, :Cc].float().reshape(T, heads, d).transpose(0, 1)
+        k_ = qk[n * T:(n + 1) * T, Cc:].float().reshape(T, heads, d).transpose(0, 1)
+        v_ = v[n * T:(n + 1) * T].float().reshape(T, heads, d).transpose(0, 1)
+        r = int(ref_index[n])
+        if r >= 0:
+            k_ = torch.cat([k_, kref[r * T:(r + 1) * T].float().reshape(T, heads, d).transpose(0, 1)], 1)
+            v_ = torch.cat([v_, vref[r * T:(r + 1) * T].float().reshape(T, heads, d).transpose(0, 1)], 1)
+        refs.append(_attn_ref(q_, k_, v_, d ** -0.5).transpose(0, 1).reshape(T, Cc))
+    close(out, torch.cat(refs, 0), f"ref_attention d={d} T={T}", rtol=4e-3, arms=4e-3)
+
+
+def test_ref_attention_growing_max():
+    """Keys whose scores grow tile after tile force the online-softmax rescale on every tile."""
+    ops = _ops()
+    heads, d, T, Nf = 1, 40, 512, 1
+    q = torch.ones(T, d).half()
+    k = (torch.arange(T).float()[:, None] / T * 0.5 * torch.ones(T, d)).half()   # score grows with key index
+    v = rnd(T, d, seed=74)
+    out = ops.ref_attention(q.to(DEV), d, k.to(DEV), d, v.t().contiguous().to(DEV), T, Nf, T, heads, d)
+    ref = _attn_ref(q.float()[None], k.float()[None], v.float()[None], d ** -0.5)[0]
+    close(out, ref, "ref_attention growing max", rtol=4e-3, arms=4e-3)
+
+
+@pytest.mark.parametrize("B,Fr,T,heads,d", [(2, 16, 10, 8, 40), (1, 4, 7, 8, 8), (1, 24, 3, 8, 160), (2, 5, 6, 2, 16),
+                                            (1, 32, 2, 8, 80)])
+def test_temporal_attention(B, Fr, T, heads, d):
+    ops = _ops()
+    Cc = heads * d
+    qkv = rnd(B * Fr * T, 3 * Cc, seed=80).to(DEV)
+    out = ops.temporal_attention(qkv, B, Fr, T, heads, d)
+    x = qkv.float().reshape(B, Fr, T, 3, heads, d)
+    q, k, v = (x[:, :, :, i].permute(0, 2, 3, 1, 4).reshape(B * T * heads, Fr, d) for i in range(3))
+    o = _attn_ref(q, k, v, d ** -0.5).reshape(B, T, heads, Fr, d).permute(0, 3, 1, 2, 4).reshape(B * Fr * T, Cc)
+    close(out, o, f"temporal_attention B{B} F{Fr} T{T} h{heads} d{d}", rtol=4e-3, arms=4e-3)
+
+
+# ------------------------------------------------------------------------------------------------
+# small / elementwise
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,silu", [(2, 320, 1280, True), (1, 7, 64, False), (2, 1280, 320, False), (16, 33, 768, True)])
+def test_linear_small(M, N, K, silu):
+    ops = _ops()
+    x = rnd(M, K, seed=90).float().to(DEV)
+    W = rnd(N, K, seed=91, scale=K ** -0.5).to(DEV)
+    b = rnd(N, seed=92).float().to(DEV)
+    out = ops.linear_small(x, W, b, silu_in=silu)
+    xin = F.silu(x) if silu else x
+    close(out, xin @ W.float().t() + b, f"linear_small {M}x{N}x{K}", rtol=1e-4, arms=1e-4)
+
+
+def test_add_and_layout():
+    ops = _ops()
+    a, b = rnd(3, 1001, seed=93).to(DEV), rnd(3, 1001, seed=94).to(DEV)
+    close(ops.add(a, b), a.float() + b.float(), "add")
+    src = rnd(2, 5, 3, 4, 6, seed=95).float().to(DEV)
+    nhwc = ops.ncfhw_to_nhwc(src)
+    close(nhwc, src.permute(0, 2, 3, 4, 1).reshape(6, 4, 6, 5), "ncfhw_to_nhwc fp32")
+    nhwc2 = ops.ncfhw_to_nhwc(src.half())
+    assert torch.equal(nhwc, nhwc2)
+    back = ops.nhwc_to_ncfhw(nhwc, 2, out_f32=True, scale=0.5, shift=0.5, clamp01=True)
+    close(back, (src.half().float() * 0.5 + 0.5).clamp(0, 1), "nhwc_to_ncfhw", rtol=1e-6, arms=1e-6)
+
+
+def test_window_accumulate_and_ddim():
+    ops = _ops()
+    S, Fw, L, HWC = 2, 4, 6, 4 * 4 * 4
+    acc = torch.zeros(S, L, HWC, device=DEV)
+    counter = torch.zeros(L, device=DEV)
+    ref_acc = torch.zeros(S, L, HWC)
+    ref_cnt = torch.zeros(L)
+    for w, frames in enumerate([[0, 1, 2, 3], [3, 4, 5, 0]]):
+        pred = rnd(S, Fw, HWC, seed=100 + w).to(DEV)
+        fi = torch.tensor(frames, dtype=torch.int32, device=DEV)
+        ops.window_accumulate(pred, acc, counter, fi, S, Fw, L, HWC)
+        ref_acc[:, frames] += pred.float().cpu()
+        ref_cnt[frames] += 1
+    close(acc, ref_acc, "window accumulate", rtol=1e-6, arms=1e-6)
+    close(counter, ref_cnt, "window counter", rtol=1e-6, arms=1e-6)
+    lat = rnd(L, HWC, seed=102).float().to(DEV)
+    lat16 = torch.empty(L, HWC, dtype=torch.float16, device=DEV)
+    x = lat.clone().cpu()
+    g, sa, sb, sap, sbp = 3.5, 0.6, 0.8, 0.7, math.sqrt(1 - 0.49)
+    ops.cfg_ddim_step(acc, counter, lat, lat16, S, L, HWC, g, sa, sb, sap, sbp)
+    eps = ref_acc / ref_cnt[None, :, None]
+    v = eps[0] + g * (eps[1] - eps[0])
+    x0 = sa * x - sb * v
+    e = sa * v + sb * x
+    ref = sap * x0 + sbp * e
+    close(lat, ref, "cfg+ddim step fp32", rtol=1e-5, arms=1e-5)
+    close(lat16, ref, "cfg+ddim step fp16 copy")
