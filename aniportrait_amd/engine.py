@@ -1,0 +1,466 @@
+"""Execution engine of the pose2vid hot path: walks the SD-1.5-topology UNets and the VAE with the HIP
+kernels of libaniportrait_hip.so (through `hipops`).  No torch arithmetic on activations here —
+torch owns memory and streams only.
+
+Layout: every activation is channels-last fp16, an image batch (N, H, W, C) == token matrix
+(N*H*W, C); N = b*f frames ordered (b f) as in the reference's `rearrange "b c f h w -> (b f) c h w"`
+(src/models/resnet.py:14, src/models/transformer_3d.py:115), so the conv<->transformer permutes of
+src/models/transformer_3d.py:128-153 do not exist here and every 1x1 conv is a plain GEMM.
+
+`PackedNet` turns a reference-format state-dict into kernel-ready device tensors once:
+3x3 conv weights [Cout][ky][kx][Cin], fused [to_q;to_k] / [to_q;to_k;to_v] projection matrices,
+GEGLU rows interleaved per 64 columns, all time_emb_proj layers stacked into one matrix, fp32 norm
+parameters and biases.
+
+Legal shortcuts relative to the reference's op sequence (identical results):
+  * reference K/V (to_k/to_v of the ReferenceNet bank) are projected once per bank update, not per
+    frame per step (src/models/mutual_self_attention.py:147-165);
+  * CFG-unconditional frames attend to their own tokens only, in the same launch (:166-186);
+  * attn2 over the length-1 CLIP sequence is softmax==1, i.e. the per-sample vector
+    to_out(to_v(e)) added in attn1's output-projection epilogue (:191-205);
+  * skip-concat / nearest-2x upsample / time-embedding add / residual adds are fused into the
+    neighbouring GroupNorm / conv / GEMM kernels.
+"""
+import math
+
+import torch
+
+from . import hipops as ops
+
+F16, F32 = torch.float16, torch.float32
+_DOWN_HAS_ATTN = (True, True, True, False)
+_UP_HAS_ATTN = (False, True, True, True)
+
+
+# ----------------------------------------------------------------------------------------------------
+# weight packing
+# ----------------------------------------------------------------------------------------------------
+
+class PackedNet:
+    """Kernel-ready weights of one network on one device.  `sd`: reference-format state-dict."""
+
+    def __init__(self, sd, device):
+        self.device = torch.device(device)
+        self.sd = sd
+        self.t = {}
+
+    # -- accessors (packed lazily, cached) ---------------------------------------------------------
+    def _raw(self, name):
+        return self.sd[name].detach()
+
+    def has(self, name):
+        return name in self.sd
+
+    def f32(self, name):
+        k = ("f32", name)
+        if k not in self.t:
+            self.t[k] = self._raw(name).to(self.device, F32).contiguous()
+        return self.t[k]
+
+    def opt_f32(self, name):
+        return self.f32(name) if name in self.sd else None
+
+    def lin(self, name):
+        """Linear / 1x1-conv weight -> fp16 [N][K]."""
+        k = ("lin", name)
+        if k not in self.t:
+            w = self._raw(name)
+            self.t[k] = w.reshape(w.shape[0], -1).to(self.device, F16).contiguous()
+        return self.t[k]
+
+    def conv3(self, name):
+        """3x3 conv weight -> fp16 [Cout][9*Cin] (tap-major)."""
+        k = ("conv3", name)
+        if k not in self.t:
+            self.t[k] = ops.pack_conv3x3(self._raw(name).to(self.device, F16))
+        return self.t[k]
+
+    def conv_small(self, name):
+        """tiny-Cin conv weight -> fp16 [Cout][k][k][Cin]."""
+        k = ("convs", name)
+        if k not in self.t:
+            self.t[k] = self._raw(name).to(self.device, F16).permute(0, 2, 3, 1).contiguous()
+        return self.t[k]
+
+    def cat_lin(self, names):
+        k = ("cat",) + tuple(names)
+        if k not in self.t:
+            self.t[k] = torch.cat([self._raw(n).to(self.device, F16) for n in names], dim=0).contiguous()
+        return self.t[k]
+
+    def geglu(self, prefix):
+        k = ("geglu", prefix)
+        if k not in self.t:
+            w = self._raw(prefix + ".weight").to(self.device, F16)
+            b = self._raw(prefix + ".bias").to(self.device, F32)
+            self.t[k] = ops.pack_geglu(w, b)
+        return self.t[k]
+
+    def pe(self, name, C):
+        """positional-encoding table fp32 [max_len][C]"""
+        k = ("pe", name)
+        if k not in self.t:
+            self.t[k] = self._raw(name).to(self.device, F32).reshape(-1, C).contiguous()
+        return self.t[k]
+
+    def temb_stack(self, names):
+        """all time_emb_proj layers stacked: W fp16 [sum Cout][temb], bias fp32, and column offsets."""
+        k = ("tembstack",)
+        if k not in self.t:
+            W = torch.cat([self._raw(n + ".weight").to(self.device, F16) for n in names], dim=0).contiguous()
+            b = torch.cat([self._raw(n + ".bias").to(self.device, F32) for n in names], dim=0).contiguous()
+            offs, o = {}, 0
+            for n in names:
+                c = self.sd[n + ".weight"].shape[0]
+                offs[n] = (o, c)
+                o += c
+            self.t[k] = (W, b, offs)
+        return self.t[k]
+
+    def vae_attn_out(self, a):
+        """to_out weight + effective bias of the VAE mid attention:  softmax rows sum to 1, so the
+        value bias commutes: P (V + 1 b_v^T) W_o^T + b_o = P V W_o^T + (W_o b_v + b_o)."""
+        k = ("vaeo", a)
+        if k not in self.t:
+            Wo = self._raw(a + ".to_out.0.weight").to(self.device, F32)
+            bo = self._raw(a + ".to_out.0.bias").to(self.device, F32)
+            bv = self._raw(a + ".to_v.bias").to(self.device, F32)
+            # the kernel sees fp16 weights; fold the bias with the same rounded matrix
+            self.t[k] = (bo + Wo.to(F16).to(F32) @ bv).contiguous()
+        return self.t[k]
+
+
+# ----------------------------------------------------------------------------------------------------
+# blocks
+# ----------------------------------------------------------------------------------------------------
+
+def resnet(net, p, x, skip, temb_rb, rows_per_group, eps, groups=32):
+    """ResnetBlock3D / ResnetBlock2D (src/models/resnet.py:218-248) on x (N,H,W,C1) [+ skip (N,H,W,C2),
+    the torch.cat of src/models/unet_3d_blocks.py:697,826 fused into norm1 and the shortcut GEMM]."""
+    N, H, W, C1 = x.shape
+    HW = H * W
+    x2 = None if skip is None else skip.reshape(N, HW, -1)
+    h = ops.groupnorm(x.reshape(N, HW, C1), net.f32(p + ".norm1.weight"), net.f32(p + ".norm1.bias"), groups, eps,
+                      True, x2=x2)
+    Cin = h.shape[-1]
+    h = ops.conv3x3(h.reshape(N, H, W, Cin), net.conv3(p + ".conv1.weight"), net.f32(p + ".conv1.bias"),
+                    rowbias=temb_rb, rows_per_group=rows_per_group)
+    Co = h.shape[-1]
+    h = ops.groupnorm(h.reshape(N, HW, Co), net.f32(p + ".norm2.weight"), net.f32(p + ".norm2.bias"), groups, eps,
+                      True)
+    if net.has(p + ".conv_shortcut.weight"):
+        sc = ops.gemm(x.reshape(N * HW, C1), net.lin(p + ".conv_shortcut.weight"), net.f32(p + ".conv_shortcut.bias"),
+                      A2=None if skip is None else skip.reshape(N * HW, -1))
+    else:
+        assert skip is None
+        sc = x.reshape(N * HW, C1)
+    return ops.conv3x3(h.reshape(N, H, W, Co), net.conv3(p + ".conv2.weight"), net.f32(p + ".conv2.bias"),
+                       residual=sc)
+
+
+def feed_forward(net, p, n_in, residual):
+    """diffusers FeedForward(geglu) + residual: GEGLU fused in the first GEMM's epilogue."""
+    wp, bp = net.geglu(p + ".net.0.proj")
+    g = ops.gemm(n_in, wp, bp, act=1)
+    return ops.gemm(g, net.lin(p + ".net.2.weight"), net.f32(p + ".net.2.bias"), residual=residual)
+
+
+class RefState:
+    """Reference-attention state of one spatial transformer block (what `module.bank` plus the hacked
+    forward's closure hold in src/models/mutual_self_attention.py:93-265)."""
+    __slots__ = ("mode", "bank", "kref", "vtref", "written")
+
+    def __init__(self):
+        self.mode = "plain"   # "plain" | "write" | "read"
+        self.bank = None      # (b, T, C) fp16 on device (read mode)
+        self.kref = None      # (b*T, C) fp16: to_k(bank)
+        self.vtref = None     # (C, b*T) fp16: to_v(bank)^T
+        self.written = None   # (b, T, C) fp16 produced in write mode
+
+
+def transformer_block(net, p, h, Nf, T, heads, attn2_vec, rows_per_sample, ref=None, ref_index=None, stop_after_bank=False):
+    """(Temporal)BasicTransformerBlock under ReferenceAttentionControl
+    (src/models/attention.py:383-445, src/models/mutual_self_attention.py:93-265).  h (Nf*T, C)."""
+    C = h.shape[1]
+    d = C // heads
+    nh = ops.layernorm(h, net.f32(p + ".norm1.weight"), net.f32(p + ".norm1.bias"))
+    mode = ref.mode if ref is not None else "plain"
+    if mode == "write":
+        ref.written = nh.reshape(Nf, T, C)
+        if stop_after_bank:
+            return None
+    qk = ops.gemm(nh, net.cat_lin((p + ".attn1.to_q.weight", p + ".attn1.to_k.weight")))
+    vt = ops.gemm(net.lin(p + ".attn1.to_v.weight"), nh)  # V^T [C][Nf*T]
+    kw = {}
+    if mode == "read" and ref.bank is not None:
+        if ref.kref is None:
+            bank2 = ref.bank.reshape(-1, C)
+            ref.kref = ops.gemm(bank2, net.lin(p + ".attn1.to_k.weight"))
+            ref.vtref = ops.gemm(net.lin(p + ".attn1.to_v.weight"), bank2)
+        assert ref.bank.shape[1] == T, "reference bank token count differs from the denoising latents"
+        kw = dict(kref=ref.kref, ldkr=C, vtref=ref.vtref, ldvtr=ref.vtref.shape[1], ref_index=ref_index)
+    a = ops.ref_attention(qk, 2 * C, qk[:, C:], 2 * C, vt, vt.shape[1], Nf, T, heads, d, **kw)
+    # attn1 out-proj + residual (+ the collapsed attn2: one vector per sample)
+    h = ops.gemm(a, net.lin(p + ".attn1.to_out.0.weight"), net.f32(p + ".attn1.to_out.0.bias"),
+                 rowbias=attn2_vec, rows_per_group=rows_per_sample, residual=h)
+    n3 = ops.layernorm(h, net.f32(p + ".norm3.weight"), net.f32(p + ".norm3.bias"))
+    return feed_forward(net, p + ".ff", n3, h)
+
+
+def spatial_transformer(net, p, x, heads, attn2_vec, frames_per_sample, ref=None, ref_index=None,
+                        stop_after_bank=False):
+    """Transformer3DModel / Transformer2DModel (src/models/transformer_3d.py:103-169): x (N,H,W,C)."""
+    N, H, W, C = x.shape
+    T = H * W
+    h = ops.groupnorm(x.reshape(N, T, C), net.f32(p + ".norm.weight"), net.f32(p + ".norm.bias"), 32, 1e-6, False)
+    h = ops.gemm(h.reshape(N * T, C), net.lin(p + ".proj_in.weight"), net.f32(p + ".proj_in.bias"))
+    h = transformer_block(net, p + ".transformer_blocks.0", h, N, T, heads, attn2_vec, frames_per_sample * T,
+                          ref, ref_index, stop_after_bank)
+    if h is None:
+        return None
+    out = ops.gemm(h, net.lin(p + ".proj_out.weight"), net.f32(p + ".proj_out.bias"), residual=x.reshape(N * T, C))
+    return out.reshape(N, H, W, C)
+
+
+def motion_module(net, p, x, b, f, heads):
+    """VanillaTemporalModule (src/models/motion_module.py:146-182,236-259,351-388): x (b*f,H,W,C)."""
+    p = p + ".temporal_transformer"
+    N, H, W, C = x.shape
+    T = H * W
+    d = C // heads
+    h = ops.groupnorm(x.reshape(N, T, C), net.f32(p + ".norm.weight"), net.f32(p + ".norm.bias"), 32, 1e-6, False)
+    h = ops.gemm(h.reshape(N * T, C), net.lin(p + ".proj_in.weight"), net.f32(p + ".proj_in.bias"))
+    bp = p + ".transformer_blocks.0"
+    i = 0
+    while net.has(bp + f".attention_blocks.{i}.to_q.weight"):
+        ap = bp + f".attention_blocks.{i}"
+        pe_name = ap + ".pos_encoder.pe"
+        pe = net.pe(pe_name, C) if net.has(pe_name) else None
+        if pe is not None and f > pe.shape[0]:
+            raise ValueError(f"video_length {f} exceeds temporal_position_encoding_max_len {pe.shape[0]}")
+        # LN + positional encoding of the frame (added to the attention INPUT: q, k and v see it; the
+        # residual below uses the un-encoded h — src/models/motion_module.py:244-254,365-366)
+        nh = ops.layernorm(h, net.f32(bp + f".norms.{i}.weight"), net.f32(bp + f".norms.{i}.bias"), pe=pe,
+                           rows_per_frame=T, frames=f)
+        qkv = ops.gemm(nh, net.cat_lin((ap + ".to_q.weight", ap + ".to_k.weight", ap + ".to_v.weight")))
+        a = ops.temporal_attention(qkv, b, f, T, heads, d)
+        h = ops.gemm(a, net.lin(ap + ".to_out.0.weight"), net.f32(ap + ".to_out.0.bias"), residual=h)
+        i += 1
+    n = ops.layernorm(h, net.f32(bp + ".ff_norm.weight"), net.f32(bp + ".ff_norm.bias"))
+    h = feed_forward(net, bp + ".ff", n, h)
+    out = ops.gemm(h, net.lin(p + ".proj_out.weight"), net.f32(p + ".proj_out.bias"), residual=x.reshape(N * T, C))
+    return out.reshape(N, H, W, C)
+
+
+# ----------------------------------------------------------------------------------------------------
+# UNets
+# ----------------------------------------------------------------------------------------------------
+
+def timestep_sinusoid(t, batch, dim, device, flip_sin_to_cos=True, freq_shift=0, max_period=10000):
+    """diffusers Timesteps / get_timestep_embedding (src/models/unet_3d.py:95-98,463-466): tiny host
+    arithmetic, fp32."""
+    if torch.is_tensor(t):
+        tt = t.detach().reshape(-1).to("cpu", torch.float32)
+    else:
+        tt = torch.tensor([float(t)], dtype=torch.float32)
+    tt = tt.expand(batch) if tt.numel() == 1 else tt
+    half = dim // 2
+    exponent = -math.log(max_period) * torch.arange(half, dtype=torch.float32) / (half - freq_shift)
+    emb = tt[:, None] * torch.exp(exponent)[None, :]
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+    if flip_sin_to_cos:
+        emb = torch.cat([emb[:, half:], emb[:, :half]], dim=-1)
+    return emb.to(device, non_blocking=True)
+
+
+def resnet_names(cfg):
+    nblk = len(cfg["block_out_channels"])
+    lpb = cfg["layers_per_block"]
+    names = [f"down_blocks.{i}.resnets.{j}" for i in range(nblk) for j in range(lpb)]
+    names += ["mid_block.resnets.0", "mid_block.resnets.1"]
+    names += [f"up_blocks.{i}.resnets.{j}" for i in range(nblk) for j in range(lpb + 1)]
+    return names
+
+
+def attention_paths(cfg):
+    """spatial transformer paths in execution order"""
+    nblk = len(cfg["block_out_channels"])
+    lpb = cfg["layers_per_block"]
+    out = [f"down_blocks.{i}.attentions.{j}" for i in range(nblk) if _DOWN_HAS_ATTN[i] for j in range(lpb)]
+    out += ["mid_block.attentions.0"]
+    out += [f"up_blocks.{i}.attentions.{j}" for i in range(nblk) if _UP_HAS_ATTN[i] for j in range(lpb + 1)]
+    return out
+
+
+class Attn2Cache:
+    """to_out(to_v(e)) of every spatial transformer block for the current CLIP embedding: constant over
+    DDIM steps, recomputed only when the embedding tensor changes."""
+
+    def __init__(self):
+        self.key = None
+        self.vecs = None
+
+    def get(self, net, cfg, ehs):
+        key = (ehs.data_ptr(), ehs._version, tuple(ehs.shape), ehs.dtype)
+        if key != self.key:
+            e = ehs.detach().reshape(ehs.shape[0], -1).to(net.device, F32).contiguous()  # (b, D): sequence length 1
+            vecs = {}
+            for p in attention_paths(cfg):
+                a = p + ".transformer_blocks.0.attn2"
+                v = ops.linear_small(e, net.lin(a + ".to_v.weight"))
+                vecs[p] = ops.linear_small(v, net.lin(a + ".to_out.0.weight"), net.f32(a + ".to_out.0.bias"))
+            self.key, self.vecs = key, vecs
+        return self.vecs
+
+
+def unet_forward(net, cfg, x, b, f, t, ehs, attn2_cache, refs, with_motion, ref_index=None, pose_nhwc=None,
+                 final=True, stop_after_last_bank=False):
+    """UNet3DConditionModel.forward (src/models/unet_3d.py:399-580) / the ReferenceNet
+    UNet2DConditionModel.forward (src/models/unet_2d_condition.py:872-1308, f = 1, no motion modules).
+
+    x (b*f, h, w, 4) fp16 channels-last.  ehs (b, 1, D).  refs: {path: RefState}.  ref_index: int32 (b*f,)
+    reference sample per frame, -1 for the CFG-unconditional frames that attend to self only
+    (src/models/mutual_self_attention.py:77-85,166-186).  pose_nhwc: list of 5 channels-last tensors or None.  Returns (b*f, h, w, out_channels) fp16 (or the last hidden state if
+    `final` is False; None if `stop_after_last_bank`).
+    """
+    if ehs.shape[1] != 1:
+        raise NotImplementedError("encoder_hidden_states with sequence length != 1: the pose2vid path feeds "
+                                  "one CLIP image token (pipeline_pose2vid_long.py:385)")
+    boc = tuple(cfg["block_out_channels"])
+    nblk, lpb = len(boc), cfg["layers_per_block"]
+    heads = cfg["attention_head_dim"]
+    eps = cfg["norm_eps"]
+    groups = cfg["norm_num_groups"]
+    N, H, W, _ = x.shape
+    assert N == b * f
+
+    emb = timestep_sinusoid(t, b, boc[0], net.device, cfg.get("flip_sin_to_cos", True), cfg.get("freq_shift", 0))
+    emb = ops.linear_small(emb, net.lin("time_embedding.linear_1.weight"), net.f32("time_embedding.linear_1.bias"))
+    emb = ops.linear_small(emb, net.lin("time_embedding.linear_2.weight"), net.f32("time_embedding.linear_2.bias"),
+                           silu_in=True)
+    Wt, bt, toffs = net.temb_stack([n + ".time_emb_proj" for n in resnet_names(cfg)])
+    temb_all = ops.linear_small(emb, Wt, bt, silu_in=True)  # (b, sum Cout) fp32
+
+    a2 = attn2_cache.get(net, cfg, ehs)
+    last_path = attention_paths(cfg)[-1]
+
+    def res(p, x, skip=None):
+        o, c = toffs[p + ".time_emb_proj"]
+        hw = x.shape[1] * x.shape[2]
+        return resnet(net, p, x, skip, temb_all[:, o:o + c], f * hw, eps, groups)
+
+    def attn(p, x):
+        return spatial_transformer(net, p, x, heads, a2[p], f, refs.get(p), ref_index,
+                                   stop_after_bank=stop_after_last_bank and p == last_path)
+
+    def mm(p, x):
+        if with_motion and net.has(p + ".temporal_transformer.proj_in.weight"):
+            return motion_module(net, p, x, b, f, cfg["motion_module_kwargs"]["num_attention_heads"])
+        return x
+
+    def add_pose(x, i):
+        if pose_nhwc is None:
+            return x
+        return ops.add(x, pose_nhwc[i])
+
+    x = ops.conv_small(x, net.conv_small("conv_in.weight"), net.f32("conv_in.bias"), 3,
+                       residual=None if pose_nhwc is None else pose_nhwc[0])
+    skips = [x]
+    for i in range(nblk):
+        for j in range(lpb):
+            x = res(f"down_blocks.{i}.resnets.{j}", x)
+            if _DOWN_HAS_ATTN[i]:
+                x = attn(f"down_blocks.{i}.attentions.{j}", x)
+            x = mm(f"down_blocks.{i}.motion_modules.{j}", x)
+            skips.append(x)
+        if i != nblk - 1:
+            pn = f"down_blocks.{i}.downsamplers.0.conv"
+            x = ops.conv3x3(x, net.conv3(pn + ".weight"), net.f32(pn + ".bias"), stride=2, pad=1)
+            skips.append(x)
+        x = add_pose(x, i + 1)
+    x = res("mid_block.resnets.0", x)
+    x = attn("mid_block.attentions.0", x)
+    x = mm("mid_block.motion_modules.0", x)
+    x = res("mid_block.resnets.1", x)
+    for i in range(nblk):
+        for j in range(lpb + 1):
+            x = res(f"up_blocks.{i}.resnets.{j}", x, skips.pop())
+            if _UP_HAS_ATTN[i]:
+                x = attn(f"up_blocks.{i}.attentions.{j}", x)
+                if x is None:
+                    return None
+            x = mm(f"up_blocks.{i}.motion_modules.{j}", x)
+        if i != nblk - 1:
+            pn = f"up_blocks.{i}.upsamplers.0.conv"
+            x = ops.conv3x3(x, net.conv3(pn + ".weight"), net.f32(pn + ".bias"), upsample=True)
+    if not final or not net.has("conv_out.weight"):
+        return x
+    C = x.shape[-1]
+    h = ops.groupnorm(x.reshape(N, H * W, C), net.f32("conv_norm_out.weight"), net.f32("conv_norm_out.bias"), groups,
+                      eps, True)
+    return ops.conv3x3(h.reshape(N, H, W, C), net.conv3("conv_out.weight"), net.f32("conv_out.bias"))
+
+
+# ----------------------------------------------------------------------------------------------------
+# VAE (diffusers AutoencoderKL, sd-vae-ft-mse topology)
+# ----------------------------------------------------------------------------------------------------
+
+def _vae_mid(net, p, x):
+    x = resnet(net, p + ".resnets.0", x, None, None, 0, 1e-6)
+    N, H, W, C = x.shape
+    T = H * W
+    a = p + ".attentions.0"
+    t = ops.groupnorm(x.reshape(N, T, C), net.f32(a + ".group_norm.weight"), net.f32(a + ".group_norm.bias"), 32,
+                      1e-6, False)
+    t2 = t.reshape(N * T, C)
+    qk = ops.gemm(t2, net.cat_lin((a + ".to_q.weight", a + ".to_k.weight")),
+                  torch.cat([net.f32(a + ".to_q.bias"), net.f32(a + ".to_k.bias")]))
+    qk3 = qk.reshape(N, T, 2 * C)
+    # single head, d = C (512): scores via batched GEMM, fp32 softmax (upcast_softmax), P V via batched GEMM
+    s = ops.gemm(qk3[:, :, :C], qk3[:, :, C:], None, batch=N, out_f32=True, alpha=C ** -0.5)
+    pm = ops.softmax_rows(s)
+    vt = ops.gemm(net.lin(a + ".to_v.weight"), t, None, batch=N)  # (N, C, T) = W_v t^T per frame
+    o = ops.gemm(pm, vt, None, batch=N)  # (N, T, C)
+    x = ops.gemm(o.reshape(N * T, C), net.lin(a + ".to_out.0.weight"), net.vae_attn_out(a),
+                 residual=x.reshape(N * T, C)).reshape(N, H, W, C)
+    return resnet(net, p + ".resnets.1", x, None, None, 0, 1e-6)
+
+
+def vae_decode(net, cfg, z):
+    """AutoencoderKL.decode(z).sample, batched over frames (src/pipelines/pipeline_pose2vid_long.py:119-120
+    decodes frame by frame; frames are independent).  z (N, h, w, 4) fp16 -> (N, 8h, 8w, 3) fp16."""
+    nb = len(cfg["block_out_channels"])
+    x = ops.conv_small(z, net.conv_small("post_quant_conv.weight"), net.f32("post_quant_conv.bias"), 1)
+    x = ops.conv_small(x, net.conv_small("decoder.conv_in.weight"), net.f32("decoder.conv_in.bias"), 3)
+    x = _vae_mid(net, "decoder.mid_block", x)
+    for i in range(nb):
+        for j in range(cfg["layers_per_block"] + 1):
+            x = resnet(net, f"decoder.up_blocks.{i}.resnets.{j}", x, None, None, 0, 1e-6)
+        if i != nb - 1:
+            pn = f"decoder.up_blocks.{i}.upsamplers.0.conv"
+            x = ops.conv3x3(x, net.conv3(pn + ".weight"), net.f32(pn + ".bias"), upsample=True)
+    N, H, W, C = x.shape
+    h = ops.groupnorm(x.reshape(N, H * W, C), net.f32("decoder.conv_norm_out.weight"),
+                      net.f32("decoder.conv_norm_out.bias"), 32, 1e-6, True)
+    return ops.conv3x3(h.reshape(N, H, W, C), net.conv3("decoder.conv_out.weight"), net.f32("decoder.conv_out.bias"))
+
+
+def vae_encode_mean(net, cfg, x):
+    """AutoencoderKL.encode(x).latent_dist.mean (src/pipelines/pipeline_pose2vid_long.py:430).
+    x (N, H, W, 3) fp16 -> (N, H/8, W/8, latent_channels) fp16."""
+    nb = len(cfg["block_out_channels"])
+    x = ops.conv_small(x, net.conv_small("encoder.conv_in.weight"), net.f32("encoder.conv_in.bias"), 3)
+    for i in range(nb):
+        for j in range(cfg["layers_per_block"]):
+            x = resnet(net, f"encoder.down_blocks.{i}.resnets.{j}", x, None, None, 0, 1e-6)
+        if i != nb - 1:
+            pn = f"encoder.down_blocks.{i}.downsamplers.0.conv"
+            x = ops.conv3x3(x, net.conv3(pn + ".weight"), net.f32(pn + ".bias"), stride=2, pad=0, pad_hi=1)
+    x = _vae_mid(net, "encoder.mid_block", x)
+    N, H, W, C = x.shape
+    h = ops.groupnorm(x.reshape(N, H * W, C), net.f32("encoder.conv_norm_out.weight"),
+                      net.f32("encoder.conv_norm_out.bias"), 32, 1e-6, True)
+    m = ops.conv3x3(h.reshape(N, H, W, C), net.conv3("encoder.conv_out.weight"), net.f32("encoder.conv_out.bias"))
+    lat2 = m.shape[-1]
+    q = ops.gemm(m.reshape(N * H * W, lat2), net.lin("quant_conv.weight"), net.f32("quant_conv.bias"))
+    return q.reshape(N, H, W, lat2)[..., : cfg["latent_channels"]].contiguous()

@@ -98,24 +98,36 @@ def layernorm(x, gamma, beta, eps=1e-5, pe=None, rows_per_frame=0, frames=0):
 
 
 def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None, act=0, out_f32=False,
-         alpha=1.0, out=None, conv=None, batch=1):
+         alpha=1.0, out=None, conv=None, batch=1, ldo=None, ldr=None):
     """out = epilogue(alpha * A @ W^T).
 
     A (M, K) fp16 [+ A2 (M, K2): K split over two sources]; W (N, K) fp16; bias (N,) fp32;
-    rowbias (M/rows_per_group, N) fp32; residual (M, N) fp16; act=1 -> GEGLU (W packed by pack_geglu).
+    rowbias (M/rows_per_group, N) fp32 (row stride = rowbias.stride(0): a column slice of a wider
+    table is fine); residual (M, N) fp16; act=1 -> GEGLU (W packed by pack_geglu).
+    A / W may be column slices of wider row-major matrices (row stride = .stride(-2)).
     conv: dict(Nimg, Hin, Win, Cin, Hout, Wout, stride, pad, upsample) -> A is the NHWC image batch.
-    batch > 1: A (B, M, K), W (B, N, K) -> out (B, M, N).
+    batch > 1: A (B, M, K) or (M, K) shared; W (B, N, K) or (N, K) shared -> out (B, M, N).
     """
     lib = L.load()
     p = L.GemmParams()
-    _req(A, F16, "A")
-    _req(W, F16, "W")
-    if batch > 1:
-        Bn, M, K = A.shape
-        N = W.shape[1]
-        p.batch, p.strideA, p.strideW, p.strideO = batch, M * K, N * K, M * N
-        p.lda = K
+    for t, nm in ((A, "A"), (W, "W")):
+        if not t.is_cuda:
+            raise L.HipLibraryError(f"{nm}: expected a GPU tensor (the hot path has no CPU fallback)")
+        if t.dtype != F16:
+            raise TypeError(f"{nm}: expected fp16, got {t.dtype}")
+        if t.stride(-1) != 1:
+            raise ValueError(f"{nm}: innermost dimension must be contiguous")
+    batched = A.dim() == 3 or W.dim() == 3
+    if batched:
+        M, K = A.shape[-2:]
+        N = W.shape[-2]
+        p.batch = batch
+        p.strideA = A.stride(0) if A.dim() == 3 else 0
+        p.strideW = W.stride(0) if W.dim() == 3 else 0
+        p.strideO = M * N
+        p.lda = A.stride(-2)
     elif conv is not None:
+        _req(A, F16, "A")
         M = conv["Nimg"] * conv["Hout"] * conv["Wout"]
         K = 9 * conv["Cin"]
         N = W.shape[0]
@@ -128,27 +140,29 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
         M, K1 = A.shape
         K = K1
         N = W.shape[0]
-        p.lda = K1
+        p.lda = A.stride(0)
         p.batch = 1
         if A2 is not None:
-            _req(A2, F16, "A2")
-            p.A2, p.lda2, p.K1 = _p(A2), A2.shape[1], K1
+            if A2.dtype != F16 or A2.stride(-1) != 1:
+                raise TypeError("A2: expected fp16 with contiguous rows")
+            p.A2, p.lda2, p.K1 = _p(A2), A2.stride(0), K1
             K = K1 + A2.shape[1]
     assert W.shape[-1] == K, f"W has K={W.shape[-1]}, expected {K}"
     n_out = N // 2 if act == 1 else N
     if out is None:
-        shape = (batch, M, n_out) if batch > 1 else (M, n_out)
+        shape = (batch, M, n_out) if batched else (M, n_out)
         out = torch.empty(shape, dtype=F32 if out_f32 else F16, device=A.device)
-    p.A, p.W, p.ldw = _p(A), _p(W), K
-    p.out, p.ldo, p.out_f32 = _p(out), n_out, int(out_f32)
+    p.A, p.W, p.ldw = _p(A), _p(W), W.stride(-2)
+    p.out, p.ldo, p.out_f32 = _p(out), int(ldo if ldo is not None else n_out), int(out_f32)
     p.M, p.N, p.K = M, N, K
     p.alpha = float(alpha)
     p.bias = _p(bias)
     if rowbias is not None:
-        p.rowbias, p.rows_per_group, p.ld_rowbias = _p(rowbias), int(rows_per_group), rowbias.shape[-1]
+        p.rowbias, p.rows_per_group, p.ld_rowbias = _p(rowbias), int(rows_per_group), rowbias.stride(0)
     if residual is not None:
-        _req(residual, F16, "residual")
-        p.residual, p.ldr = _p(residual), n_out
+        if residual.dtype != F16:
+            raise TypeError("residual: expected fp16")
+        p.residual, p.ldr = _p(residual), int(ldr if ldr is not None else n_out)
     p.act = int(act)
     L.check(lib.anip_gemm(C.byref(p), _stream()), "anip_gemm")
     return out

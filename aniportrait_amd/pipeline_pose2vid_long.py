@@ -1,0 +1,385 @@
+"""`Pose2VideoPipeline` — the reference's pipeline call surface
+(src/pipelines/pipeline_pose2vid_long.py:39-80,338-363,584; short variant in pipeline_pose2vid.py) driving the
+MI355X hot path: ReferenceNet single pass -> T DDIM steps x context windows of the denoising UNet3D ->
+batched VAE decode, all on HIP kernels behind `aniportrait_amd.engine`.
+
+Differences from the reference's op sequence that leave results unchanged:
+PoseGuider features are computed once per window (they do not depend on t); latents / per-frame
+accumulators stay channels-last on the device for the whole loop; window accumulation, the
+`noise_pred / counter` division, CFG and the DDIM v-prediction update are two fused kernels
+(`anip_window_accumulate`, `anip_cfg_ddim_step`) in fp32; frames are decoded in batches.
+
+Extra keyword arguments (all optional, reference callers never pass them):
+  latents=         (1, 4, L, h, w) initial noise, injected instead of `prepare_latents` (parity tests);
+  dp_group=        torch.distributed process group: shard the context windows of this clip over its ranks
+                   (aniportrait_amd.distributed); every rank must make the same call;
+  decode_chunk=    frames per VAE decode batch (default 16).
+"""
+import inspect
+import math
+
+import numpy as np
+import torch
+
+from . import distributed as D
+from . import hipops as ops
+from .autoencoder_kl import AutoencoderKL
+from .context import get_context_scheduler
+from .image_processor import VaeImageProcessor, randn_tensor
+from .modeling import BaseOutput
+from .mutual_self_attention import ReferenceAttentionControl
+
+
+class Pose2VideoPipelineOutput(BaseOutput):
+    """videos: torch.Tensor (1, 3, L, H, W) fp32 in [0, 1] on the CPU (pipeline_pose2vid_long.py:31-33)"""
+
+
+class _Progress:
+    def __init__(self, total, disable=False):
+        self.bar = None
+        if not disable:
+            try:
+                from tqdm.auto import tqdm
+                self.bar = tqdm(total=total)
+            except Exception:  # pragma: no cover
+                self.bar = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        if self.bar is not None:
+            self.bar.close()
+
+    def update(self, n=1):
+        if self.bar is not None:
+            self.bar.update(n)
+
+
+class Pose2VideoPipeline:
+    _optional_components = []
+    _long = True
+
+    def __init__(self, vae, image_encoder, reference_unet, denoising_unet, pose_guider, scheduler,
+                 image_proj_model=None, tokenizer=None, text_encoder=None):
+        self._names = []
+        self.register_modules(vae=vae, image_encoder=image_encoder, reference_unet=reference_unet,
+                              denoising_unet=denoising_unet, pose_guider=pose_guider, scheduler=scheduler,
+                              image_proj_model=image_proj_model, tokenizer=tokenizer, text_encoder=text_encoder)
+        self.vae_scale_factor = 2 ** (len(self.vae.config.block_out_channels) - 1)
+        from transformers import CLIPImageProcessor
+        self.clip_image_processor = CLIPImageProcessor()
+        self.ref_image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor, do_convert_rgb=True)
+        self.cond_image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor, do_convert_rgb=True,
+                                                      do_normalize=True)
+        self._progress_disabled = False
+        self._hip_vae = None
+
+    # -- DiffusionPipeline surface -------------------------------------------------------------------
+    def register_modules(self, **kw):
+        for k, v in kw.items():
+            setattr(self, k, v)
+            if k not in self._names:
+                self._names.append(k)
+
+    @property
+    def components(self):
+        return {k: getattr(self, k) for k in self._names}
+
+    def to(self, *args, **kwargs):
+        """`.to(device)`, `.to(device, dtype)`, `.to(dtype=...)` on every nn.Module component"""
+        device = kwargs.pop("device", None)
+        dtype = kwargs.pop("dtype", None) or kwargs.pop("torch_dtype", None)
+        for a in args:
+            if isinstance(a, torch.dtype):
+                dtype = a
+            else:
+                device = a
+        for k in self._names:
+            m = getattr(self, k)
+            if isinstance(m, torch.nn.Module):
+                m.to(device=device, dtype=dtype)
+        self._hip_vae = None
+        return self
+
+    @property
+    def device(self):
+        for k in self._names:
+            m = getattr(self, k)
+            if isinstance(m, torch.nn.Module):
+                return next(m.parameters()).device
+        return torch.device("cpu")
+
+    @property
+    def _execution_device(self):
+        return self.device
+
+    def progress_bar(self, iterable=None, total=None):
+        return _Progress(total, self._progress_disabled)
+
+    def set_progress_bar_config(self, **kw):
+        self._progress_disabled = bool(kw.get("disable", False))
+
+    def enable_vae_slicing(self):
+        self.vae.enable_slicing()
+
+    def disable_vae_slicing(self):
+        self.vae.disable_slicing()
+
+    # -- helpers kept from the reference ----------------------------------------------------------------
+    def prepare_extra_step_kwargs(self, generator, eta):
+        """pipeline_pose2vid_long.py:128-147"""
+        kw = {}
+        params = set(inspect.signature(self.scheduler.step).parameters.keys())
+        if "eta" in params:
+            kw["eta"] = eta
+        if "generator" in params:
+            kw["generator"] = generator
+        return kw
+
+    def prepare_latents(self, batch_size, num_channels_latents, width, height, video_length, dtype, device, generator,
+                        latents=None):
+        """pipeline_pose2vid_long.py:149-183"""
+        shape = (batch_size, num_channels_latents, video_length, height // self.vae_scale_factor,
+                 width // self.vae_scale_factor)
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an "
+                             f"effective batch size of {batch_size}. Make sure the batch size matches the length of "
+                             "the generators.")
+        if latents is None:
+            latents = randn_tensor(shape, generator=generator, device=device, dtype=dtype)
+        else:
+            if tuple(latents.shape) != shape:
+                raise ValueError(f"latents have shape {tuple(latents.shape)}, expected {shape}")
+            latents = latents.to(device)
+        return latents * self.scheduler.init_noise_sigma
+
+    def _vae(self):
+        """the HIP VAE; a foreign (diffusers) AutoencoderKL is adopted once via its state-dict"""
+        if isinstance(self.vae, AutoencoderKL):
+            return self.vae
+        if self._hip_vae is None:
+            self._hip_vae = AutoencoderKL.from_module(self.vae)
+        return self._hip_vae
+
+    def decode_latents(self, latents, decode_chunk=16):
+        """latents (1, 4, L, h, w) -> numpy (1, 3, L, H, W) fp32 in [0, 1] (pipeline_pose2vid_long.py:113-126)"""
+        b, c, f, h, w = latents.shape
+        z = ops.ncfhw_to_nhwc((latents.to(self.device).float() * (1 / 0.18215)).contiguous())
+        return self._decode_nhwc(z, b, decode_chunk).cpu().float().numpy()
+
+    def _decode_nhwc(self, z, b, decode_chunk=16):
+        """z (b*L, h, w, 4) fp16 (already divided by the scaling factor) -> (b, 3, L, H, W) fp16 in [0,1]"""
+        vae = self._vae()
+        outs = []
+        for s in range(0, z.shape[0], decode_chunk):
+            outs.append(vae.decode_nhwc(z[s:s + decode_chunk].contiguous()))
+        x = torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
+        return ops.nhwc_to_ncfhw(x, b, out_f32=False, scale=0.5, shift=0.5, clamp01=True)
+
+    def interpolate_latents(self, latents, interpolation_factor, device):
+        """pipeline_pose2vid_long.py:293-336: a no-op at the default factor (the only value the scripts use)"""
+        if interpolation_factor < 2:
+            return latents
+        raise NotImplementedError("interpolation_factor >= 2 is dead at the reference's defaults (SURVEY.md §2.1 #14)")
+
+    # -- stages ---------------------------------------------------------------------------------------
+    def _clip_embeds(self, ref_image, device):
+        clip_image = self.clip_image_processor.preprocess(ref_image.resize((224, 224)), return_tensors="pt").pixel_values
+        enc = self.image_encoder
+        p = next(enc.parameters())
+        return enc(clip_image.to(p.device, dtype=p.dtype)).image_embeds.to(device)
+
+    def _fused_step_coefficients(self, t):
+        sch = self.scheduler
+        if hasattr(sch, "coefficients"):
+            return sch.coefficients(t)
+        # a foreign (diffusers) DDIMScheduler with the same configuration
+        cfg = sch.config
+        if type(sch).__name__ != "DDIMScheduler" or cfg.prediction_type != "v_prediction" or cfg.clip_sample:
+            raise NotImplementedError("the fused CFG+DDIM kernel implements DDIMScheduler / v_prediction / "
+                                      "clip_sample=False (configs/inference/inference_v2.yaml:24-33)")
+        prev = int(t) - cfg.num_train_timesteps // sch.num_inference_steps
+        a_t = float(sch.alphas_cumprod[int(t)])
+        a_p = float(sch.alphas_cumprod[prev]) if prev >= 0 else float(sch.final_alpha_cumprod)
+        return math.sqrt(a_t), math.sqrt(max(1 - a_t, 0.0)), math.sqrt(a_p), math.sqrt(max(1 - a_p, 0.0))
+
+    @torch.no_grad()
+    def _run(self, ref_image, pose_images, ref_pose_image, width, height, video_length, num_inference_steps,
+             guidance_scale, num_images_per_prompt, eta, generator, output_type, return_dict, callback, callback_steps,
+             windows_fn, latents=None, dp_group=None, decode_chunk=16, return_latents=False):
+        device = self._execution_device
+        if device.type != "cuda":
+            raise RuntimeError("Pose2VideoPipeline: the denoising path only runs on an MI355X (HIP kernels); "
+                               "call pipe.to('cuda') — there is no CPU fallback")
+        if num_images_per_prompt != 1:
+            raise NotImplementedError("num_images_per_prompt != 1")
+        if eta != 0.0:
+            raise NotImplementedError("eta != 0")
+        do_cfg = guidance_scale > 1.0
+        S = 2 if do_cfg else 1
+        rank, ws = D.world(dp_group) if dp_group is not None else (0, 1)
+
+        sch = self.scheduler
+        try:
+            sch.set_timesteps(num_inference_steps, device="cpu")
+        except TypeError:  # pragma: no cover
+            sch.set_timesteps(num_inference_steps)
+        timesteps = [int(t) for t in sch.timesteps.tolist()]
+
+        # CLIP image embedding -> one token per sample (uncond = zeros)
+        clip_image_embeds = self._clip_embeds(ref_image, device)
+        ehs = clip_image_embeds.unsqueeze(1)
+        if do_cfg:
+            ehs = torch.cat([torch.zeros_like(ehs), ehs], dim=0)
+        ehs = ehs.contiguous()
+
+        writer = ReferenceAttentionControl(self.reference_unet, do_classifier_free_guidance=do_cfg, mode="write",
+                                           batch_size=1, fusion_blocks="full")
+        reader = ReferenceAttentionControl(self.denoising_unet, do_classifier_free_guidance=do_cfg, mode="read",
+                                           batch_size=1, fusion_blocks="full")
+
+        C = self.denoising_unet.in_channels
+        lat = self.prepare_latents(1, C, width, height, video_length, clip_image_embeds.dtype, device, generator,
+                                   latents)
+        self.prepare_extra_step_kwargs(generator, eta)
+        L = lat.shape[2]
+        h, w = lat.shape[3], lat.shape[4]
+        HWC = h * w * C
+        # channels-last fp32 master copy [L][h*w*C] + fp16 copy fed to the UNet
+        lat16 = ops.ncfhw_to_nhwc(lat.float().contiguous())          # (L, h, w, C) fp16
+        lat32 = lat.float().permute(0, 2, 3, 4, 1).reshape(L, HWC).contiguous()
+
+        # reference image -> VAE latent mean * 0.18215
+        vae = self._vae()
+        ref_t = self.ref_image_processor.preprocess(ref_image, height=height, width=width).to(device)
+        ref_lat = vae.encode_mean_nhwc(ops.ncfhw_to_nhwc(ref_t.float().unsqueeze(2).contiguous()))
+        ref_lat = (ref_lat.float() * 0.18215).half()                 # (1, h, w, 4)
+
+        # pose condition images (numpy path of VaeImageProcessor: values in [-1, 509], see image_processor.py)
+        pg = self.pose_guider
+        pose = torch.cat([self.cond_image_processor.preprocess(p, height=height, width=width).unsqueeze(2)
+                          for p in pose_images], dim=2).to(device=device, dtype=pg.dtype)
+        ref_pose = self.cond_image_processor.preprocess(ref_pose_image, height=height, width=width)
+        ref_pose = ref_pose.to(device=device, dtype=pg.dtype)
+
+        # ReferenceNet: one pass at t = 0 (pipeline_pose2vid_long.py:474-485); only the banks matter, so
+        # the pass stops after the last bank write.  With a dp_group, rank 0 computes and broadcasts.
+        if rank == 0 or ws == 1:
+            self.reference_unet.forward_nhwc(ref_lat.repeat(S, 1, 1, 1).contiguous(), S, 1, 0, ehs, None,
+                                             final=False, stop_after_last_bank=True)
+        if ws > 1:
+            self._broadcast_banks(writer, S, h, w, dp_group, device)
+        reader.update(writer)
+
+        windows = [list(c) for c in windows_fn(L, num_inference_steps)]
+        my_windows = D.shard_round_robin(len(windows), rank, ws) if ws > 1 else list(range(len(windows)))
+        win_idx = {k: torch.tensor(windows[k], dtype=torch.int32, device=device) for k in my_windows}
+        pose_cache = {}
+
+        def pose_features(k):
+            if k not in pose_cache:
+                c = windows[k]
+                fea = pg(pose[:, :, c], ref_pose)                    # batch 1: CFG duplication does not change
+                out = []                                             # train-mode BatchNorm statistics
+                for t_ in fea:
+                    n = ops.ncfhw_to_nhwc(t_.contiguous())
+                    out.append(n.repeat(S, 1, 1, 1).contiguous() if S > 1 else n)
+                pose_cache[k] = out
+            return pose_cache[k]
+
+        acc = torch.empty((S, L, HWC), dtype=torch.float32, device=device)
+        counter = torch.empty((L,), dtype=torch.float32, device=device)
+        single = len(windows) == 1 and windows[0] == list(range(L))
+        with self.progress_bar(total=num_inference_steps) as bar:
+            for i, t in enumerate(timesteps):
+                acc.zero_()
+                counter.zero_()
+                for k in my_windows:
+                    c = windows[k]
+                    x = lat16 if single else lat16[win_idx[k].long()]
+                    x = x.repeat(S, 1, 1, 1).contiguous() if S > 1 else x
+                    pred = self.denoising_unet.forward_nhwc(x, S, len(c), t, ehs[:S], pose_features(k))
+                    ops.window_accumulate(pred, acc, counter, win_idx[k], S, len(c), L, HWC)
+                if ws > 1 and len(windows) > 1:
+                    D.allreduce_window_sums(acc, counter, dp_group)
+                sa, sb, sap, sbp = self._fused_step_coefficients(t)
+                ops.cfg_ddim_step(acc, counter, lat32, lat16, S, L, HWC, guidance_scale, sa, sb, sap, sbp)
+                bar.update()
+                if callback is not None and i % callback_steps == 0:
+                    callback(i, t, lat32.reshape(1, L, h, w, C).permute(0, 4, 1, 2, 3).contiguous())
+        reader.clear()
+        writer.clear()
+
+        final = lat32.reshape(1, L, h, w, C).permute(0, 4, 1, 2, 3).contiguous()
+        if return_latents:
+            return final
+        z = (lat32 * (1 / 0.18215)).half().reshape(L, h, w, C)
+        if ws > 1:
+            mine = D.shard_round_robin(L, rank, ws)
+            sel = torch.tensor(mine, dtype=torch.long, device=device)
+            part = self._decode_nhwc(z[sel].contiguous(), 1, decode_chunk)          # (1, 3, n_local, H, W)
+            frames = D.gather_frames(part[0].permute(1, 0, 2, 3).contiguous(), mine, L, 0, dp_group)
+            video = None if frames is None else frames.permute(1, 0, 2, 3).unsqueeze(0)
+        else:
+            video = self._decode_nhwc(z, 1, decode_chunk)
+        if video is None:
+            return None
+        images = video.cpu().float().numpy()
+        if output_type == "tensor":
+            images = torch.from_numpy(images)
+        if not return_dict:
+            return images
+        return Pose2VideoPipelineOutput(videos=images)
+
+    def _broadcast_banks(self, writer, S, h, w, group, device):
+        """rank 0 holds the 16 banks; other ranks allocate same-shaped tensors; one flat RCCL broadcast."""
+        unet = self.reference_unet
+        rank, _ = D.world(group)
+        shapes = bank_shapes(unet.config, S, h, w)  # derived identically on every rank from the topology
+        tensors = []
+        for p in writer._paths():
+            node = unet._ref_blocks[p].node
+            if rank != 0:
+                node.bank = [torch.empty(shapes[p], dtype=torch.float16, device=device)]
+            assert tuple(node.bank[0].shape) == tuple(shapes[p]), (p, tuple(node.bank[0].shape), shapes[p])
+            tensors.append(node.bank[0])
+        D.broadcast_tensors(tensors, 0, group)
+
+    # -- public call -----------------------------------------------------------------------------------
+    def __call__(self, ref_image, pose_images, ref_pose_image, width, height, video_length, num_inference_steps,
+                 guidance_scale, num_images_per_prompt=1, eta=0.0, generator=None, output_type="tensor",
+                 return_dict=True, callback=None, callback_steps=1, context_schedule="uniform", context_frames=16,
+                 context_stride=1, context_overlap=4, context_batch_size=1, interpolation_factor=1, **kwargs):
+        if context_batch_size != 1:
+            raise NotImplementedError("context_batch_size must stay 1 (the reference's bank repeat assumes it, "
+                                      "pipeline_pose2vid_long.py:541)")
+        self.interpolate_latents(None, interpolation_factor, None)
+        scheduler_fn = get_context_scheduler(context_schedule)
+
+        def windows_fn(L, steps):
+            return scheduler_fn(0, steps, L, context_frames, context_stride, context_overlap)
+
+        return self._run(ref_image, pose_images, ref_pose_image, width, height, video_length, num_inference_steps,
+                         guidance_scale, num_images_per_prompt, eta, generator, output_type, return_dict, callback,
+                         callback_steps, windows_fn, **kwargs)
+
+
+def bank_shapes(unet_cfg, S, h, w):
+    """{hooked block path: (S, tokens, channels)} of the ReferenceNet banks for an (h, w) latent."""
+    from .engine import attention_paths
+    boc = tuple(unet_cfg["block_out_channels"])
+    out = {}
+    for p in attention_paths(unet_cfg):
+        parts = p.split(".")
+        if parts[0] == "down_blocks":
+            lvl = int(parts[1])
+        elif parts[0] == "mid_block":
+            lvl = len(boc) - 1
+        else:
+            lvl = len(boc) - 1 - int(parts[1])
+        hh, ww = h, w
+        for _ in range(lvl):
+            hh, ww = (hh + 1) // 2, (ww + 1) // 2
+        out[p] = (S, hh * ww, boc[lvl])
+    return out
