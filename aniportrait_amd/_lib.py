@@ -61,7 +61,11 @@ SIGNATURES = {
     "anip_ncfhw_to_nhwc": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_void_p]),
     "anip_nhwc_to_ncfhw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_float, c_float, c_int,
                                    c_void_p]),
+    "anip_profile_enable": (c_int, [c_int]),
+    "anip_profile_collect": (c_int, [c_int, C.POINTER(c_int64), C.POINTER(C.c_double)]),
+    "anip_profile_kernel_name": (C.c_char_p, [c_int]),
 }
+N_KERNEL_IDS = 11  # ANIP_K_COUNT
 
 _lib = None
 
@@ -75,6 +79,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64; import it FIRST so that this library's HIP symbols resolve to
+    # the runtime torch already initialised (two HIP runtimes in one process do not share devices,
+    # streams or allocations: launches then fail with "no ROCm-capable device is detected")
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise HipLibraryError(
             f"{LIB_PATH} not found: build it with `python -m aniportrait_amd.build` (hipcc, gfx950). "

@@ -4,6 +4,8 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <vector>
+
 #include "../../include/aniportrait_hip.h"
 
 static thread_local char g_err[512] = "";
@@ -38,4 +40,66 @@ extern "C" int anip_device_info(char* arch, int arch_len, int* num_cu) {
   }
   if (num_cu) *num_cu = prop.multiProcessorCount;
   return 0;
+}
+
+// ---- per-kernel HIP-event profiling -------------------------------------------------------------
+namespace {
+struct ProfRec {
+  int kid;
+  hipEvent_t a, b;
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+const char* const kKernelNames[ANIP_K_COUNT] = {
+    "gemm_kernel<false>", "gemm_kernel<true> (conv3x3)", "gn_stats_kernel", "gn_apply_kernel", "layernorm_kernel",
+    "ref_attn_kernel", "temporal_attn_kernel", "softmax_rows_kernel", "conv_small_kernel", "linear_small_kernel",
+    "elementwise"};
+}  // namespace
+
+void anip_prof_begin(int kid, hipStream_t s) {
+  if (!g_prof_on) return;
+  ProfRec r;
+  r.kid = kid;
+  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+  (void)hipEventRecord(r.a, s);
+  g_prof.push_back(r);
+}
+
+void anip_prof_end(int kid, hipStream_t s) {
+  if (!g_prof_on || g_prof.empty()) return;
+  ProfRec& r = g_prof.back();
+  if (r.kid == kid) (void)hipEventRecord(r.b, s);
+}
+
+extern "C" int anip_profile_enable(int on) {
+  g_prof_on = on != 0;
+  return 0;
+}
+
+extern "C" int anip_profile_collect(int max_ids, int64_t* launches, double* total_ms) {
+  for (int i = 0; i < max_ids; ++i) {
+    launches[i] = 0;
+    total_ms[i] = 0.0;
+  }
+  int rc = 0;
+  for (ProfRec& r : g_prof) {
+    float ms = 0.f;
+    hipError_t e = hipEventSynchronize(r.b);
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, r.a, r.b);
+    if (e != hipSuccess) {
+      anip_set_error("anip_profile_collect: %s", hipGetErrorString(e));
+      rc = -2;
+    } else if (r.kid >= 0 && r.kid < max_ids) {
+      launches[r.kid] += 1;
+      total_ms[r.kid] += (double)ms;
+    }
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  g_prof.clear();
+  return rc;
+}
+
+extern "C" const char* anip_profile_kernel_name(int kid) {
+  return (kid >= 0 && kid < ANIP_K_COUNT) ? kKernelNames[kid] : "?";
 }

@@ -232,6 +232,7 @@ __global__ __launch_bounds__(NT, (D > 96 ? 1 : 2)) void ref_attn_kernel(const Re
 template <int D>
 int launch_ref_attn(const RefAttnArgs& a, int Nf, hipStream_t stream) {
   dim3 grid((unsigned)((a.T + 127) / 128), (unsigned)a.heads, (unsigned)Nf);
+  AnipProfScope prof_(ANIP_K_REF_ATTN, (void*)stream);
   hipLaunchKernelGGL(ref_attn_kernel<D>, grid, dim3(NT), 0, stream, a);
   return 0;
 }
@@ -376,8 +377,11 @@ extern "C" int anip_temporal_attention(const void* qkv, void* out, int B, int F,
   ANIP_REQUIRE(per_wave * wpb <= 65536, "anip_temporal_attention: LDS budget exceeded (F=%d d=%d)", F, d);
   const int64_t nprob = (int64_t)B * T * heads;
   const int64_t blocks = cdiv64(nprob, wpb);
-  hipLaunchKernelGGL(temporal_attn_kernel, dim3((unsigned)blocks), dim3(NT), per_wave * wpb, (hipStream_t)stream,
-                     (const f16*)qkv, (f16*)out, B, F, T, heads, d, scale, wpb, nprob);
+  {
+    AnipProfScope prof_(ANIP_K_TEMPORAL_ATTN, (void*)stream);
+    hipLaunchKernelGGL(temporal_attn_kernel, dim3((unsigned)blocks), dim3(NT), per_wave * wpb, (hipStream_t)stream,
+                       (const f16*)qkv, (f16*)out, B, F, T, heads, d, scale, wpb, nprob);
+  }
   ANIP_LAUNCH_CHECK("anip_temporal_attention");
   return 0;
 }

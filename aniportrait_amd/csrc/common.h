@@ -34,6 +34,16 @@ void anip_set_error(const char* fmt, ...);
     }                                                                        \
   } while (0)
 
+// per-launch HIP-event bracket (no-op unless anip_profile_enable(1)); see api.cpp
+void anip_prof_begin(int kid, hipStream_t s);
+void anip_prof_end(int kid, hipStream_t s);
+struct AnipProfScope {
+  int kid;
+  hipStream_t s;
+  AnipProfScope(int k, void* st) : kid(k), s((hipStream_t)st) { anip_prof_begin(kid, s); }
+  ~AnipProfScope() { anip_prof_end(kid, s); }
+};
+
 // NOTE: native ext_vector types only — selects on HIP's struct uint4 are lowered through scratch.
 union U4H8 {
   u32x4 u;

@@ -217,8 +217,11 @@ extern "C" int anip_conv_small(const void* x, const void* w, const float* bias, 
   if (ppb > 1024) ppb = 1024;
   const int64_t npix = (int64_t)N * H * W;
   const int64_t blocks = cdiv64(npix, ppb);
-  hipLaunchKernelGGL(conv_small_kernel, dim3((unsigned)blocks), dim3(NT), lds, (hipStream_t)stream, (const f16*)x,
-                     (const f16*)w, bias, (const f16*)residual, (f16*)y, N, H, W, Cin, Cout, ksize, ppb);
+  {
+    AnipProfScope prof_(ANIP_K_CONV_SMALL, (void*)stream);
+    hipLaunchKernelGGL(conv_small_kernel, dim3((unsigned)blocks), dim3(NT), lds, (hipStream_t)stream, (const f16*)x,
+                       (const f16*)w, bias, (const f16*)residual, (f16*)y, N, H, W, Cin, Cout, ksize, ppb);
+  }
   ANIP_LAUNCH_CHECK("anip_conv_small");
   return 0;
 }
@@ -229,8 +232,11 @@ extern "C" int anip_linear_small(const float* x, const void* W, const float* bia
   ANIP_REQUIRE(M >= 1 && M <= 16, "anip_linear_small: M=%d must be in [1,16]", M);
   ANIP_REQUIRE((K & 7) == 0, "anip_linear_small: K=%d must be a multiple of 8", K);
   const int blocks = (N + NT / 64 - 1) / (NT / 64);
-  hipLaunchKernelGGL(linear_small_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, x, (const f16*)W, bias, y,
-                     M, N, K, silu_in);
+  {
+    AnipProfScope prof_(ANIP_K_LINEAR_SMALL, (void*)stream);
+    hipLaunchKernelGGL(linear_small_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, x, (const f16*)W, bias, y,
+                       M, N, K, silu_in);
+  }
   ANIP_LAUNCH_CHECK("anip_linear_small");
   return 0;
 }
@@ -239,8 +245,11 @@ extern "C" int anip_add(const void* a, const void* b, void* out, int64_t n, void
   ANIP_REQUIRE(a && b && out && n > 0, "anip_add: bad arguments");
   ANIP_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0, "anip_add: pointers must be 16-B aligned");
   const int64_t nvec = n / 8;
-  hipLaunchKernelGGL(add_kernel, dim3(grid_for(nvec)), dim3(NT), 0, (hipStream_t)stream, (const f16*)a, (const f16*)b,
-                     (f16*)out, nvec, n);
+  {
+    AnipProfScope prof_(ANIP_K_ELEMENTWISE, (void*)stream);
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(nvec)), dim3(NT), 0, (hipStream_t)stream, (const f16*)a, (const f16*)b,
+                       (f16*)out, nvec, n);
+  }
   ANIP_LAUNCH_CHECK("anip_add");
   return 0;
 }
@@ -249,8 +258,11 @@ extern "C" int anip_window_accumulate(const void* pred, float* acc, float* count
                                       int L, int64_t HWC, void* stream) {
   ANIP_REQUIRE(pred && acc && counter && frames, "anip_window_accumulate: null pointer");
   ANIP_REQUIRE(S >= 1 && Fw >= 1 && Fw <= NT && L >= Fw, "anip_window_accumulate: bad sizes S=%d Fw=%d L=%d", S, Fw, L);
-  hipLaunchKernelGGL(window_accumulate_kernel, dim3(grid_for((int64_t)S * Fw * HWC)), dim3(NT), 0,
-                     (hipStream_t)stream, (const f16*)pred, acc, counter, frames, S, Fw, L, HWC);
+  {
+    AnipProfScope prof_(ANIP_K_ELEMENTWISE, (void*)stream);
+    hipLaunchKernelGGL(window_accumulate_kernel, dim3(grid_for((int64_t)S * Fw * HWC)), dim3(NT), 0,
+                       (hipStream_t)stream, (const f16*)pred, acc, counter, frames, S, Fw, L, HWC);
+  }
   ANIP_LAUNCH_CHECK("anip_window_accumulate");
   return 0;
 }
@@ -260,8 +272,11 @@ extern "C" int anip_cfg_ddim_step(const float* acc, const float* counter, float*
                                   float sqrt_b_prev, void* stream) {
   ANIP_REQUIRE(acc && counter && latents, "anip_cfg_ddim_step: null pointer");
   ANIP_REQUIRE(S == 1 || S == 2, "anip_cfg_ddim_step: S must be 1 or 2");
-  hipLaunchKernelGGL(cfg_ddim_kernel, dim3(grid_for((int64_t)L * HWC)), dim3(NT), 0, (hipStream_t)stream, acc, counter,
-                     latents, (f16*)latents_f16, S, L, HWC, guidance, sqrt_a, sqrt_b, sqrt_a_prev, sqrt_b_prev);
+  {
+    AnipProfScope prof_(ANIP_K_ELEMENTWISE, (void*)stream);
+    hipLaunchKernelGGL(cfg_ddim_kernel, dim3(grid_for((int64_t)L * HWC)), dim3(NT), 0, (hipStream_t)stream, acc, counter,
+                       latents, (f16*)latents_f16, S, L, HWC, guidance, sqrt_a, sqrt_b, sqrt_a_prev, sqrt_b_prev);
+  }
   ANIP_LAUNCH_CHECK("anip_cfg_ddim_step");
   return 0;
 }
@@ -270,6 +285,7 @@ extern "C" int anip_ncfhw_to_nhwc(const void* src, int src_f32, void* dst, int B
                                   void* stream) {
   ANIP_REQUIRE(src && dst && B > 0 && C > 0 && F > 0 && HW > 0, "anip_ncfhw_to_nhwc: bad arguments");
   const int64_t total = (int64_t)B * C * F * HW;
+  AnipProfScope prof_(ANIP_K_ELEMENTWISE, stream);
   if (src_f32)
     hipLaunchKernelGGL(ncfhw_to_nhwc_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
                        (const float*)src, (f16*)dst, B, C, F, HW);
@@ -284,6 +300,7 @@ extern "C" int anip_nhwc_to_ncfhw(const void* src, void* dst, int dst_f32, int B
                                   float scale, float shift, int clamp01, void* stream) {
   ANIP_REQUIRE(src && dst && B > 0 && C > 0 && F > 0 && HW > 0, "anip_nhwc_to_ncfhw: bad arguments");
   const int64_t total = (int64_t)B * C * F * HW;
+  AnipProfScope prof_(ANIP_K_ELEMENTWISE, stream);
   if (dst_f32)
     hipLaunchKernelGGL(nhwc_to_ncfhw_kernel<float>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
                        (const f16*)src, (float*)dst, B, C, F, HW, scale, shift, clamp01);

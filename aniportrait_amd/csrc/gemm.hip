@@ -316,10 +316,13 @@ extern "C" int anip_gemm(const anip_gemm_params* pp, void* stream) {
   }
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   dim3 grid((unsigned)(nbm * nbn), (unsigned)p.batch, 1);
-  if (p.conv)
-    hipLaunchKernelGGL(gemm_kernel<true>, grid, dim3(NTHREADS), 0, (hipStream_t)stream, p);
-  else
-    hipLaunchKernelGGL(gemm_kernel<false>, grid, dim3(NTHREADS), 0, (hipStream_t)stream, p);
+  {
+    AnipProfScope prof_(p.conv ? ANIP_K_CONV3X3 : ANIP_K_GEMM, stream);
+    if (p.conv)
+      hipLaunchKernelGGL(gemm_kernel<true>, grid, dim3(NTHREADS), 0, (hipStream_t)stream, p);
+    else
+      hipLaunchKernelGGL(gemm_kernel<false>, grid, dim3(NTHREADS), 0, (hipStream_t)stream, p);
+  }
   ANIP_LAUNCH_CHECK("anip_gemm");
   return 0;
 }

@@ -274,8 +274,11 @@ extern "C" int anip_groupnorm(const void* x1, int C1, const void* x2, int C2, co
   const int rows_par = CV <= NT ? NT / CV : 1;
   const size_t sm1 = (size_t)rows_par * C * 2 * sizeof(float);
   ANIP_REQUIRE(sm1 <= 65536, "anip_groupnorm: stats LDS %zu too large", sm1);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, N), dim3(NT), sm1, (hipStream_t)stream, (const f16*)x1, C1,
-                     (const f16*)x2, C2, HW, G, ppc, ws);
+  {
+    AnipProfScope prof_(ANIP_K_GN_STATS, (void*)stream);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, N), dim3(NT), sm1, (hipStream_t)stream, (const f16*)x1, C1,
+                       (const f16*)x2, C2, HW, G, ppc, ws);
+  }
   ANIP_LAUNCH_CHECK("anip_groupnorm(stats)");
   // apply: ~2048 pixels*C/8 vectors per block at least, >= 1024 blocks when possible
   int64_t want = (2048 + N - 1) / N;
@@ -285,8 +288,11 @@ extern "C" int anip_groupnorm(const void* x1, int C1, const void* x2, int C2, co
   const int64_t ppa = (HW + ac - 1) / ac;
   const int achunks = (int)((HW + ppa - 1) / ppa);
   const size_t sm2 = (size_t)(2 * C + 2 * G) * sizeof(float);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(achunks, N), dim3(NT), sm2, (hipStream_t)stream, (const f16*)x1, C1,
-                     (const f16*)x2, C2, gamma, beta, (f16*)y, HW, G, eps, silu, (const float*)ws, nchunks, ppa);
+  {
+    AnipProfScope prof_(ANIP_K_GN_APPLY, (void*)stream);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(achunks, N), dim3(NT), sm2, (hipStream_t)stream, (const f16*)x1, C1,
+                       (const f16*)x2, C2, gamma, beta, (f16*)y, HW, G, eps, silu, (const float*)ws, nchunks, ppa);
+  }
   ANIP_LAUNCH_CHECK("anip_groupnorm(apply)");
   return 0;
 }
@@ -297,15 +303,21 @@ extern "C" int anip_layernorm(const void* x, const float* gamma, const float* be
   ANIP_REQUIRE(M > 0 && C > 0 && (C & 7) == 0 && C <= LN_MAXCH * 512, "anip_layernorm: bad C=%d (multiple of 8, <= %d)", C, LN_MAXCH * 512);
   if (pe != nullptr) ANIP_REQUIRE(rows_per_frame > 0 && F > 0, "anip_layernorm: pe needs rows_per_frame, F");
   const int64_t blocks = cdiv64(M, NT / 64);
-  hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, (const f16*)x, gamma,
-                     beta, (f16*)y, M, C, eps, pe, rows_per_frame, F);
+  {
+    AnipProfScope prof_(ANIP_K_LAYERNORM, (void*)stream);
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, (const f16*)x, gamma,
+                       beta, (f16*)y, M, C, eps, pe, rows_per_frame, F);
+  }
   ANIP_LAUNCH_CHECK("anip_layernorm");
   return 0;
 }
 
 extern "C" int anip_softmax_rows(const float* s, void* p, int64_t rows, int cols, void* stream) {
   ANIP_REQUIRE(s && p && rows > 0 && cols > 0, "anip_softmax_rows: bad arguments");
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(NT), 0, (hipStream_t)stream, s, (f16*)p, cols);
+  {
+    AnipProfScope prof_(ANIP_K_SOFTMAX, (void*)stream);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(NT), 0, (hipStream_t)stream, s, (f16*)p, cols);
+  }
   ANIP_LAUNCH_CHECK("anip_softmax_rows");
   return 0;
 }

@@ -195,10 +195,13 @@ def transformer_block(net, p, h, Nf, T, heads, attn2_vec, rows_per_sample, ref=N
     if mode == "read" and ref.bank is not None:
         if ref.kref is None:
             bank2 = ref.bank.reshape(-1, C)
+            if bank2.dtype != F16 or bank2.device != net.device:
+                bank2 = bank2.to(net.device, F16)
             ref.kref = ops.gemm(bank2, net.lin(p + ".attn1.to_k.weight"))
             ref.vtref = ops.gemm(net.lin(p + ".attn1.to_v.weight"), bank2)
         assert ref.bank.shape[1] == T, "reference bank token count differs from the denoising latents"
-        kw = dict(kref=ref.kref, ldkr=C, vtref=ref.vtref, ldvtr=ref.vtref.shape[1], ref_index=ref_index)
+        kw = dict(kref=ref.kref, ldkr=C, vtref=ref.vtref, ldvtr=ref.vtref.shape[1], ref_index=ref_index[0],
+                  n_ref_frames=ref_index[1])
     a = ops.ref_attention(qk, 2 * C, qk[:, C:], 2 * C, vt, vt.shape[1], Nf, T, heads, d, **kw)
     # attn1 out-proj + residual (+ the collapsed attn2: one vector per sample)
     h = ops.gemm(a, net.lin(p + ".attn1.to_out.0.weight"), net.f32(p + ".attn1.to_out.0.bias"),
@@ -318,9 +321,9 @@ def unet_forward(net, cfg, x, b, f, t, ehs, attn2_cache, refs, with_motion, ref_
     """UNet3DConditionModel.forward (src/models/unet_3d.py:399-580) / the ReferenceNet
     UNet2DConditionModel.forward (src/models/unet_2d_condition.py:872-1308, f = 1, no motion modules).
 
-    x (b*f, h, w, 4) fp16 channels-last.  ehs (b, 1, D).  refs: {path: RefState}.  ref_index: int32 (b*f,)
+    x (b*f, h, w, 4) fp16 channels-last.  ehs (b, 1, D).  refs: {path: RefState}.  ref_index: (int32 tensor (b*f,), n) —
     reference sample per frame, -1 for the CFG-unconditional frames that attend to self only
-    (src/models/mutual_self_attention.py:77-85,166-186).  pose_nhwc: list of 5 channels-last tensors or None.  Returns (b*f, h, w, out_channels) fp16 (or the last hidden state if
+    (src/models/mutual_self_attention.py:77-85,166-186), and the number n of frames that do have one.  pose_nhwc: list of 5 channels-last tensors or None.  Returns (b*f, h, w, out_channels) fp16 (or the last hidden state if
     `final` is False; None if `stop_after_last_bank`).
     """
     if ehs.shape[1] != 1:

@@ -33,6 +33,58 @@ def _req(t, dtype, name):
     return t
 
 
+# ------------------------------------------------------------------------------------------------
+# per-kernel profiling (HIP events in the library + algorithmic work counted here)
+# ------------------------------------------------------------------------------------------------
+K_GEMM, K_CONV3X3, K_GN_STATS, K_GN_APPLY, K_LAYERNORM, K_REF_ATTN, K_TEMPORAL_ATTN, K_SOFTMAX = range(8)
+_WORK = None  # kernel id -> algorithmic work (flops for 0,1,5; bytes otherwise) while profiling
+
+
+def _work(kid, amount):
+    if _WORK is not None:
+        _WORK[kid] = _WORK.get(kid, 0) + amount
+
+
+class profile:
+    """`with profile() as p: ...; p.result` -> {kernel name: {launches, ms, work, unit, rate}}.
+    Every kernel launch inside the block is bracketed by HIP events on its stream (library side);
+    `work` is the algorithmic FLOP (contractions) or byte (HBM-bound kernels) count of those launches."""
+
+    def __enter__(self):
+        global _WORK
+        lib = L.load()
+        torch.cuda.synchronize()
+        lib.anip_profile_collect(0, None, None)  # drop stale records
+        lib.anip_profile_enable(1)
+        _WORK = {}
+        self.result = None
+        return self
+
+    def __exit__(self, *exc):
+        global _WORK
+        lib = L.load()
+        lib.anip_profile_enable(0)
+        n = L.N_KERNEL_IDS
+        launches = (C.c_int64 * n)()
+        ms = (C.c_double * n)()
+        rc = lib.anip_profile_collect(n, launches, ms)
+        work, _WORK = _WORK, None
+        if exc[0] is None:
+            L.check(rc, "anip_profile_collect")
+        res = {}
+        for k in range(n):
+            if launches[k] == 0:
+                continue
+            flops = k in (K_GEMM, K_CONV3X3, K_REF_ATTN)
+            w = work.get(k, 0)
+            t = ms[k] * 1e-3
+            res[lib.anip_profile_kernel_name(k).decode()] = dict(
+                id=k, launches=int(launches[k]), ms=ms[k], work=w, unit="TFLOP/s" if flops else "GB/s",
+                rate=(w / t / (1e12 if flops else 1e9)) if t > 0 else 0.0)
+        self.result = res
+        return False
+
+
 def device_info():
     lib = L.load()
     buf = C.create_string_buffer(64)
@@ -81,6 +133,8 @@ def groupnorm(x1, gamma, beta, groups, eps, silu, x2=None):
     Ctot = C1 + C2
     y = torch.empty((N, HW, Ctot), dtype=F16, device=x1.device)
     ws = torch.empty((lib.anip_groupnorm_ws_floats(N, HW, Ctot, groups),), dtype=F32, device=x1.device)
+    _work(K_GN_STATS, N * HW * Ctot * 2)
+    _work(K_GN_APPLY, N * HW * Ctot * 4)
     L.check(lib.anip_groupnorm(_p(x1), C1, _p(x2), C2, _p(_req(gamma, F32, "gamma")), _p(_req(beta, F32, "beta")),
                                _p(y), N, HW, groups, float(eps), int(bool(silu)), _p(ws), _stream()),
             "anip_groupnorm")
@@ -92,6 +146,7 @@ def layernorm(x, gamma, beta, eps=1e-5, pe=None, rows_per_frame=0, frames=0):
     _req(x, F16, "x")
     M, Cc = x.shape
     y = torch.empty_like(x)
+    _work(K_LAYERNORM, M * Cc * 4)
     L.check(lib.anip_layernorm(_p(x), _p(_req(gamma, F32, "gamma")), _p(_req(beta, F32, "beta")), _p(y), M, Cc,
                                float(eps), _p(pe), int(rows_per_frame), int(frames), _stream()), "anip_layernorm")
     return y
@@ -164,6 +219,7 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
             raise TypeError("residual: expected fp16")
         p.residual, p.ldr = _p(residual), int(ldr if ldr is not None else n_out)
     p.act = int(act)
+    _work(K_CONV3X3 if conv is not None else K_GEMM, 2 * M * N * K * max(1, int(p.batch)))
     L.check(lib.anip_gemm(C.byref(p), _stream()), "anip_gemm")
     return out
 
@@ -199,9 +255,11 @@ def conv_small(x, w, bias, ksize, residual=None):
 
 
 def ref_attention(q, ldq, k, ldk, vt, ldvt, n_frames, T, heads, d, kref=None, ldkr=0, vtref=None, ldvtr=0,
-                  ref_index=None, scale=None):
-    """see anip_ref_attention; returns (n_frames*T, heads*d) fp16."""
+                  ref_index=None, scale=None, n_ref_frames=0):
+    """see anip_ref_attention; returns (n_frames*T, heads*d) fp16.  `n_ref_frames` (frames whose
+    ref_index >= 0) is only used for the profiler's FLOP count."""
     lib = L.load()
+    _work(K_REF_ATTN, 4 * T * T * heads * d * (n_frames + (n_ref_frames if ref_index is not None else 0)))
     out = torch.empty((n_frames * T, heads * d), dtype=F16, device=q.device)
     if scale is None:
         scale = d ** -0.5
@@ -217,6 +275,7 @@ def temporal_attention(qkv, B, F, T, heads, d, scale=None):
     out = torch.empty((B * F * T, heads * d), dtype=F16, device=qkv.device)
     if scale is None:
         scale = d ** -0.5
+    _work(K_TEMPORAL_ATTN, B * F * T * heads * d * 4 * 2)
     L.check(lib.anip_temporal_attention(_p(qkv), _p(out), B, F, T, heads, d, float(scale), _stream()),
             "anip_temporal_attention")
     return out
@@ -227,6 +286,7 @@ def softmax_rows(s):
     _req(s, F32, "s")
     rows = s.numel() // s.shape[-1]
     p = torch.empty(s.shape, dtype=F16, device=s.device)
+    _work(K_SOFTMAX, s.numel() * 6)
     L.check(lib.anip_softmax_rows(_p(s), _p(p), rows, s.shape[-1], _stream()), "anip_softmax_rows")
     return p
 

@@ -260,8 +260,25 @@ def sinusoidal_pe(d_model, max_len):
     return pe
 
 
+_SKIP_INIT = False
+
+
+class skip_init:
+    """`with skip_init(): Model(...)` leaves parameters uninitialised (checkpoint / synthetic fill follows)."""
+
+    def __enter__(self):
+        global _SKIP_INIT
+        self.prev, _SKIP_INIT = _SKIP_INIT, True
+
+    def __exit__(self, *a):
+        global _SKIP_INIT
+        _SKIP_INIT = self.prev
+
+
 def _default_init(name, shape):
     """PyTorch-default-like init (values only matter until a checkpoint is loaded)."""
+    if _SKIP_INIT:
+        return torch.empty(shape)
     leaf = name.rsplit(".", 1)[-1]
     if len(shape) >= 2:
         fan_in = 1

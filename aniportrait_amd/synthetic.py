@@ -101,3 +101,26 @@ def synth_latents(L, h, w, seed=42, channels=4):
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)
     return torch.randn((1, channels, L, h, w), generator=g, dtype=torch.float32)
+
+
+@torch.no_grad()
+def fast_fill_(module, seed=0):
+    """Random fill ON the module's device (bench.py: no checkpoints, values only need to be well-scaled):
+    weights ~ N(0, 1/fan_in), norm gammas 1 + 0.1 N, biases / betas 0.1 N.  Not reproducible across
+    devices; parity tests use the name-hash `fill_module_` instead."""
+    dev = next(module.parameters()).device
+    g = torch.Generator(device=dev)
+    g.manual_seed(1000 + seed)
+    for name, p in module.named_parameters():
+        leaf = name.rsplit(".", 1)[-1]
+        r = torch.randn(p.shape, generator=g, device=dev, dtype=torch.float32)
+        if p.dim() >= 2:
+            r.mul_(1.0 / math.sqrt(int(np.prod(p.shape[1:]))))
+        elif leaf == "weight":
+            r.mul_(0.1).add_(1.0)
+        elif leaf == "scale":
+            r.fill_(1.5)
+        else:
+            r.mul_(0.1)
+        p.copy_(r.to(p.dtype))
+    return module

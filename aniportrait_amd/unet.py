@@ -107,7 +107,7 @@ class _UNetBase(HipModel):
         nb = next(r.bank.shape[0] for r in refs.values() if r.mode == "read" and r.bank is not None)
         if int(idx.max()) >= nb:
             raise ValueError(f"reference bank holds {nb} sample(s) but the batch addresses sample {int(idx.max())}")
-        return idx.to(device)
+        return idx.to(device), int((idx >= 0).sum())
 
     def _check_unsupported(self, **kw):
         for k, v in kw.items():

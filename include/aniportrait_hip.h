@@ -135,6 +135,29 @@ int anip_ncfhw_to_nhwc(const void* src, int src_f32, void* dst, int B, int C, in
 int anip_nhwc_to_ncfhw(const void* src, void* dst, int dst_f32, int B, int C, int F, int64_t HW, float scale,
                        float shift, int clamp01, void* stream);
 
+/* ---- per-kernel timing with HIP events (bench.py's roofline leg) -------------------------------------
+ * When enabled, every entry point brackets each kernel launch with hipEventRecord on the launch stream.
+ * anip_profile_collect synchronises, sums elapsed time and launch count per kernel family
+ * (ANIP_K_* index), writes up to max_ids entries, then clears the records.  Off by default: the timed
+ * region of bench.py runs without events. */
+enum {
+  ANIP_K_GEMM = 0,        /* gemm_kernel<false>: Linear / 1x1 conv / batched GEMM */
+  ANIP_K_CONV3X3 = 1,     /* gemm_kernel<true>: implicit-GEMM 3x3 convolution */
+  ANIP_K_GN_STATS = 2,
+  ANIP_K_GN_APPLY = 3,
+  ANIP_K_LAYERNORM = 4,
+  ANIP_K_REF_ATTN = 5,
+  ANIP_K_TEMPORAL_ATTN = 6,
+  ANIP_K_SOFTMAX = 7,
+  ANIP_K_CONV_SMALL = 8,
+  ANIP_K_LINEAR_SMALL = 9,
+  ANIP_K_ELEMENTWISE = 10, /* add / window accumulate / cfg+ddim / layout conversions */
+  ANIP_K_COUNT = 11
+};
+int anip_profile_enable(int on);
+int anip_profile_collect(int max_ids, int64_t* launches, double* total_ms);
+const char* anip_profile_kernel_name(int kid);
+
 #ifdef __cplusplus
 }
 #endif

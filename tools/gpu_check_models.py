@@ -18,24 +18,7 @@ from util import load_golden, oracle_state_dicts, rel_err  # noqa: E402
 DEV = "cuda"
 
 
-def build(small, keys=("denoising_unet", "reference_unet", "vae", "pose_guider"), dtype=torch.float16):
-    sds = oracle_state_dicts(small, keys=list(keys))
-    m = {}
-    if "denoising_unet" in keys:
-        m["denoising_unet"] = UNet3DConditionModel(**C.unet3d_kwargs(small))
-    if "reference_unet" in keys:
-        m["reference_unet"] = UNet2DConditionModel(**C.unet2d_kwargs(small))
-    if "vae" in keys:
-        m["vae"] = AutoencoderKL(**(C.SD_VAE_SMALL if small else C.SD_VAE_FT_MSE))
-    if "pose_guider" in keys:
-        ch0 = (C.SD15_UNET_SMALL if small else C.SD15_UNET)["block_out_channels"][0]
-        m["pose_guider"] = PoseGuider(noise_latent_channels=ch0, use_ca=True)
-    for k in m:
-        missing, unexpected = m[k].load_state_dict(sds[k], strict=False)
-        assert not unexpected, unexpected[:3]
-        assert all(x.endswith((".pe", "running_mean", "running_var", "num_batches_tracked")) for x in missing), missing[:3]
-        m[k] = m[k].to(DEV, dtype)
-    return m, sds
+from util import build_hip_models as build  # noqa: E402,F401
 
 
 def report(tag, out, ref):

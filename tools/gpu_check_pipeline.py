@@ -17,10 +17,7 @@ from util import load_golden  # noqa: E402
 DEV = "cuda"
 
 
-def small_clip():
-    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
-    enc = CLIPVisionModelWithProjection(CLIPVisionConfig(**C.CLIP_SMALL))
-    return fill_module_(enc, 0, "image_encoder.").eval().to(DEV)
+from util import small_clip_encoder as small_clip  # noqa: E402,F401
 
 
 def psnr(a, b):
