@@ -9,7 +9,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libaniportrait_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -31,6 +31,7 @@ class GemmParams(C.Structure):
         ("batch", c_int), ("strideA", c_int64), ("strideW", c_int64), ("strideO", c_int64),
         ("conv", c_int), ("Nimg", c_int), ("Hin", c_int), ("Win", c_int), ("Cin", c_int),
         ("Hout", c_int), ("Wout", c_int), ("stride", c_int), ("pad", c_int), ("upsample", c_int),
+        ("trans_out", c_int),
     ]
 
 

@@ -149,42 +149,45 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const f16* __restrict__ x1
 }
 
 // ---------------------------------------------------------------------------------------------
-// LayerNorm: one wave per row, two-pass in registers. C <= 2560, C % 8 == 0.
+// LayerNorm: G lanes (power of two) cooperate on one row, 64/G rows per wave, so that every lane is
+// busy for any channel count: lane l of a group owns the 16-B chunks l, l+G, l+2G, ... (NCH of them,
+// kept in registers between the mean pass and the variance pass).  C % 8 == 0, C <= 2560.
+// G is chosen on the host as the smallest power of two with ceil(C/8 / G) <= 5.
 // ---------------------------------------------------------------------------------------------
-constexpr int LN_MAXCH = 5;  // 5 chunks * 8 * 64 lanes = 2560 channels
+constexpr int LN_MAXCH = 5;  // chunks of 8 channels per lane
 
+template <int G, int NCH>
 __global__ __launch_bounds__(NT) void layernorm_kernel(const f16* __restrict__ x, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, f16* __restrict__ y, int64_t M,
                                                       int C, float eps, const float* __restrict__ pe,
                                                       int64_t rows_per_frame, int F) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
-  if (row >= M) return;
+  constexpr int RPB = NT / G;  // rows per block
+  const int gl = threadIdx.x % G;
+  const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / G;
+  const bool rvalid = row < M;
   const int CV = C >> 3;
-  const f16* xr = x + row * C;
-  float v[LN_MAXCH][8];
+  const f16* xr = x + (rvalid ? row : 0) * C;
+  float v[NCH][8];
   float s = 0.f;
 #pragma unroll
-  for (int k = 0; k < LN_MAXCH; ++k) {
-    const int cv = lane + 64 * k;
-    if (cv < CV) {
-      U4H8 t;
-      t.u = *(const u32x4*)(xr + cv * 8);
+  for (int k = 0; k < NCH; ++k) {
+    const int cv = gl + G * k;
+    U4H8 t;
+    t.u = u32x4{0u, 0u, 0u, 0u};
+    if (rvalid && cv < CV) t.u = *(const u32x4*)(xr + cv * 8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        v[k][e] = (float)t.e[e];
-        s += v[k][e];
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[k][e] = 0.f;
+    for (int e = 0; e < 8; ++e) {
+      v[k][e] = (float)t.e[e];
+      s += v[k][e];
     }
   }
-  const float mean = wave_sum(s) / (float)C;
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / (float)C;
   float q = 0.f;
 #pragma unroll
-  for (int k = 0; k < LN_MAXCH; ++k) {
-    const int cv = lane + 64 * k;
+  for (int k = 0; k < NCH; ++k) {
+    const int cv = gl + G * k;
     if (cv < CV) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -193,24 +196,46 @@ __global__ __launch_bounds__(NT) void layernorm_kernel(const f16* __restrict__ x
       }
     }
   }
-  const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = rsqrtf(q / (float)C + eps);
+  if (!rvalid) return;
   const float* per = nullptr;
   if (pe != nullptr) per = pe + ((row / rows_per_frame) % F) * C;
   f16* yr = y + row * C;
 #pragma unroll
-  for (int k = 0; k < LN_MAXCH; ++k) {
-    const int cv = lane + 64 * k;
+  for (int k = 0; k < NCH; ++k) {
+    const int cv = gl + G * k;
     if (cv < CV) {
       const int c = cv * 8;
+      const float4 g0 = *(const float4*)(gamma + c), g1 = *(const float4*)(gamma + c + 4);
+      const float4 b0 = *(const float4*)(beta + c), b1 = *(const float4*)(beta + c + 4);
+      const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
       U4H8 o;
+      if (per != nullptr) {
+        const float4 p0 = *(const float4*)(per + c), p1 = *(const float4*)(per + c + 4);
+        const float pp[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float f = (v[k][e] - mean) * rstd * gamma[c + e] + beta[c + e];
-        if (per != nullptr) f += per[c + e];
-        o.e[e] = (f16)f;
+        for (int e = 0; e < 8; ++e) o.e[e] = (f16)((v[k][e] - mean) * rstd * gg[e] + bb[e] + pp[e]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.e[e] = (f16)((v[k][e] - mean) * rstd * gg[e] + bb[e]);
       }
       *(u32x4*)(yr + c) = o.u;
     }
+  }
+}
+
+template <int G>
+void launch_layernorm(int nch, dim3 grid, hipStream_t st, const f16* x, const float* gamma, const float* beta, f16* y,
+                      int64_t M, int C, float eps, const float* pe, int64_t rpf, int F) {
+  switch (nch) {
+    case 1: hipLaunchKernelGGL((layernorm_kernel<G, 1>), grid, dim3(NT), 0, st, x, gamma, beta, y, M, C, eps, pe, rpf, F); break;
+    case 2: hipLaunchKernelGGL((layernorm_kernel<G, 2>), grid, dim3(NT), 0, st, x, gamma, beta, y, M, C, eps, pe, rpf, F); break;
+    case 3: hipLaunchKernelGGL((layernorm_kernel<G, 3>), grid, dim3(NT), 0, st, x, gamma, beta, y, M, C, eps, pe, rpf, F); break;
+    case 4: hipLaunchKernelGGL((layernorm_kernel<G, 4>), grid, dim3(NT), 0, st, x, gamma, beta, y, M, C, eps, pe, rpf, F); break;
+    default: hipLaunchKernelGGL((layernorm_kernel<G, 5>), grid, dim3(NT), 0, st, x, gamma, beta, y, M, C, eps, pe, rpf, F); break;
   }
 }
 
@@ -302,11 +327,24 @@ extern "C" int anip_layernorm(const void* x, const float* gamma, const float* be
   ANIP_REQUIRE(x && y && gamma && beta, "anip_layernorm: null pointer");
   ANIP_REQUIRE(M > 0 && C > 0 && (C & 7) == 0 && C <= LN_MAXCH * 512, "anip_layernorm: bad C=%d (multiple of 8, <= %d)", C, LN_MAXCH * 512);
   if (pe != nullptr) ANIP_REQUIRE(rows_per_frame > 0 && F > 0, "anip_layernorm: pe needs rows_per_frame, F");
-  const int64_t blocks = cdiv64(M, NT / 64);
+  ANIP_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)pe) & 15) == 0,
+               "anip_layernorm: pointers must be 16-B aligned");
+  const int CV = C / 8;
+  int G = 8;
+  while (G < 64 && (CV + G - 1) / G > LN_MAXCH) G <<= 1;
+  const int nch = (CV + G - 1) / G;
+  const dim3 grid((unsigned)cdiv64(M, NT / G));
   {
     AnipProfScope prof_(ANIP_K_LAYERNORM, (void*)stream);
-    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(NT), 0, (hipStream_t)stream, (const f16*)x, gamma,
-                       beta, (f16*)y, M, C, eps, pe, rows_per_frame, F);
+    hipStream_t st = (hipStream_t)stream;
+    const f16* xx = (const f16*)x;
+    f16* yy = (f16*)y;
+    switch (G) {
+      case 8: launch_layernorm<8>(nch, grid, st, xx, gamma, beta, yy, M, C, eps, pe, rows_per_frame, F); break;
+      case 16: launch_layernorm<16>(nch, grid, st, xx, gamma, beta, yy, M, C, eps, pe, rows_per_frame, F); break;
+      case 32: launch_layernorm<32>(nch, grid, st, xx, gamma, beta, yy, M, C, eps, pe, rows_per_frame, F); break;
+      default: launch_layernorm<64>(nch, grid, st, xx, gamma, beta, yy, M, C, eps, pe, rows_per_frame, F); break;
+    }
   }
   ANIP_LAUNCH_CHECK("anip_layernorm");
   return 0;

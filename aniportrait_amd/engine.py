@@ -190,7 +190,7 @@ def transformer_block(net, p, h, Nf, T, heads, attn2_vec, rows_per_sample, ref=N
         if stop_after_bank:
             return None
     qk = ops.gemm(nh, net.cat_lin((p + ".attn1.to_q.weight", p + ".attn1.to_k.weight")))
-    vt = ops.gemm(net.lin(p + ".attn1.to_v.weight"), nh)  # V^T [C][Nf*T]
+    vt = ops.gemm(nh, net.lin(p + ".attn1.to_v.weight"), trans_out=True)  # V^T [C][Nf*T]
     kw = {}
     if mode == "read" and ref.bank is not None:
         if ref.kref is None:
@@ -198,7 +198,7 @@ def transformer_block(net, p, h, Nf, T, heads, attn2_vec, rows_per_sample, ref=N
             if bank2.dtype != F16 or bank2.device != net.device:
                 bank2 = bank2.to(net.device, F16)
             ref.kref = ops.gemm(bank2, net.lin(p + ".attn1.to_k.weight"))
-            ref.vtref = ops.gemm(net.lin(p + ".attn1.to_v.weight"), bank2)
+            ref.vtref = ops.gemm(bank2, net.lin(p + ".attn1.to_v.weight"), trans_out=True)
         assert ref.bank.shape[1] == T, "reference bank token count differs from the denoising latents"
         kw = dict(kref=ref.kref, ldkr=C, vtref=ref.vtref, ldvtr=ref.vtref.shape[1], ref_index=ref_index[0],
                   n_ref_frames=ref_index[1])

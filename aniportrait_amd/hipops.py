@@ -153,7 +153,7 @@ def layernorm(x, gamma, beta, eps=1e-5, pe=None, rows_per_frame=0, frames=0):
 
 
 def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None, act=0, out_f32=False,
-         alpha=1.0, out=None, conv=None, batch=1, ldo=None, ldr=None):
+         alpha=1.0, out=None, conv=None, batch=1, ldo=None, ldr=None, trans_out=False):
     """out = epilogue(alpha * A @ W^T).
 
     A (M, K) fp16 [+ A2 (M, K2): K split over two sources]; W (N, K) fp16; bias (N,) fp32;
@@ -162,6 +162,7 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
     A / W may be column slices of wider row-major matrices (row stride = .stride(-2)).
     conv: dict(Nimg, Hin, Win, Cin, Hout, Wout, stride, pad, upsample) -> A is the NHWC image batch.
     batch > 1: A (B, M, K) or (M, K) shared; W (B, N, K) or (N, K) shared -> out (B, M, N).
+    trans_out: return the transposed result (N, M) (bias only, fp16).
     """
     lib = L.load()
     p = L.GemmParams()
@@ -204,6 +205,12 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
             K = K1 + A2.shape[1]
     assert W.shape[-1] == K, f"W has K={W.shape[-1]}, expected {K}"
     n_out = N // 2 if act == 1 else N
+    if trans_out:
+        assert not batched and act == 0 and not out_f32 and residual is None and rowbias is None
+        if out is None:
+            out = torch.empty((N, M), dtype=F16, device=A.device)
+        p.trans_out = 1
+        ldo = M if ldo is None else ldo
     if out is None:
         shape = (batch, M, n_out) if batched else (M, n_out)
         out = torch.empty(shape, dtype=F32 if out_f32 else F16, device=A.device)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ANIP_ABI_VERSION 1
+#define ANIP_ABI_VERSION 2
 
 int anip_version(void);
 const char* anip_last_error(void);
@@ -78,6 +78,8 @@ typedef struct anip_gemm_params {
   /* implicit 3x3 convolution (conv != 0): A is an NHWC image batch, M = Nimg*Hout*Wout, K = 9*Cin,
    * W = [Cout][3][3][Cin].  upsample=1 fuses nearest-2x (resnet.py:72-74) into the gather. */
   int conv; int Nimg, Hin, Win, Cin, Hout, Wout, stride, pad, upsample;
+  int trans_out;                         /* 1: store the result transposed, out[n*ldo + m] (fp16; bias only):
+                                            V^T = (x W_v^T)^T for anip_ref_attention */
 } anip_gemm_params;
 int anip_gemm(const anip_gemm_params* p, void* stream);
 

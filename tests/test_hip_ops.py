@@ -345,3 +345,117 @@ def test_window_accumulate_and_ddim():
     ref = sap * x0 + sbp * e
     close(lat, ref, "cfg+ddim step fp32", rtol=1e-5, arms=1e-5)
     close(lat16, ref, "cfg+ddim step fp16 copy")
+
+
+# ------------------------------------------------------------------------------------------------
+# gemm2 (the main 256 x BN LDS-DMA kernel): problems large enough to be dispatched to it (M >= 1024 and
+# >= 128 tiles), every loader / epilogue variant, ragged M / N / K tails
+# ------------------------------------------------------------------------------------------------
+def _ref_mm(A, W):
+    return (A.double().cpu() @ W.double().cpu().t()).float()
+
+
+@pytest.mark.parametrize("M,N,K", [(32768, 320, 320), (33003, 328, 136), (16384, 2560, 64), (40000, 640, 1280),
+                                   (4096, 4096, 512)])
+def test_gemm2_plain(M, N, K):
+    ops = _ops()
+    A = rnd(M, K, seed=101).to(DEV)
+    W = rnd(N, K, seed=102, scale=K ** -0.5).to(DEV)
+    bias = rnd(N, seed=103).float().to(DEV)
+    out = ops.gemm(A, W, bias)
+    close(out, _ref_mm(A, W) + bias.cpu(), f"gemm2 {M}x{N}x{K}")
+
+
+def test_gemm2_epilogues_and_two_source():
+    ops = _ops()
+    M, K1, K2, N = 40960, 320, 640, 320
+    A1 = rnd(M, K1, seed=104).to(DEV)
+    A2 = rnd(M, K2, seed=105).to(DEV)
+    W = rnd(N, K1 + K2, seed=106, scale=(K1 + K2) ** -0.5).to(DEV)
+    bias = rnd(N, seed=107).float().to(DEV)
+    rowbias = rnd(5, N, seed=108).float().to(DEV)
+    res = rnd(M, N, seed=109).to(DEV)
+    base = _ref_mm(torch.cat([A1, A2], 1), W)
+    out = ops.gemm(A1, W, bias, A2=A2, rowbias=rowbias, rows_per_group=8192, residual=res)
+    ref = base + bias.cpu() + rowbias.cpu().repeat_interleave(8192, dim=0) + res.float().cpu()
+    close(out, ref, "gemm2 two-source + bias + rowbias + residual")
+    out = ops.gemm(A1, W[:, :K1].contiguous(), None, alpha=0.125, out_f32=True)
+    close(out, 0.125 * _ref_mm(A1, W[:, :K1]), "gemm2 alpha fp32-out", rtol=1e-4, arms=1e-4)
+    # column slices of wider matrices as operands (q | k halves of the fused projection)
+    qk = rnd(M, 2 * K1, seed=110).to(DEV)
+    out = ops.gemm(qk[:, K1:], W[:, :K1].contiguous())
+    close(out, _ref_mm(qk[:, K1:], W[:, :K1]), "gemm2 strided A")
+
+
+def test_gemm2_geglu():
+    ops = _ops()
+    M, Cc = 36000, 320
+    A = rnd(M, Cc, seed=111).to(DEV)
+    W = rnd(8 * Cc, Cc, seed=112, scale=Cc ** -0.5)
+    b = rnd(8 * Cc, seed=113).float()
+    Wp, bp = ops.pack_geglu(W, b)
+    out = ops.gemm(A, Wp.to(DEV), bp.to(DEV), act=1)
+    h, g = (_ref_mm(A, W) + b).chunk(2, dim=-1)
+    close(out, h * F.gelu(g), "gemm2 GEGLU")
+
+
+@pytest.mark.parametrize("M,N,K", [(32768, 320, 320), (20001, 160, 96), (300, 72, 64)])
+def test_gemm_transposed_out(M, N, K):
+    """V^T projection: out[n][m] (large -> gemm2, small -> the 128x128 kernel)"""
+    ops = _ops()
+    A = rnd(M, K, seed=114).to(DEV)
+    W = rnd(N, K, seed=115, scale=K ** -0.5).to(DEV)
+    bias = rnd(N, seed=116).float().to(DEV)
+    out = ops.gemm(A, W, bias, trans_out=True)
+    assert out.shape == (N, M)
+    close(out, (_ref_mm(A, W) + bias.cpu()).t(), f"gemm trans_out {M}x{N}x{K}")
+
+
+def test_gemm2_batched():
+    ops = _ops()
+    B, M, N, K = 4, 16384, 256, 512
+    A = rnd(B, M, K, seed=117).to(DEV)
+    W = rnd(B, N, K, seed=118, scale=K ** -0.5).to(DEV)
+    out = ops.gemm(A, W, None, batch=B)
+    close(out, torch.bmm(A.double().cpu(), W.double().cpu().transpose(1, 2)).float(), "gemm2 batched")
+    Ws = rnd(N, K, seed=119, scale=K ** -0.5).to(DEV)
+    out = ops.gemm(A, Ws, None, batch=B)   # shared W
+    close(out, (A.double().cpu() @ Ws.double().cpu().t()).float(), "gemm2 batched shared W")
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,stride,pad,pad_hi,up", [
+    (8, 64, 64, 64, 128, 1, 1, 1, False), (5, 61, 67, 128, 320, 1, 1, 1, False), (8, 64, 64, 64, 64, 2, 1, 1, False),
+    (4, 32, 32, 128, 64, 1, 1, 1, True), (6, 65, 65, 64, 96, 2, 0, 1, False), (2, 128, 128, 64, 3, 1, 1, 1, False),
+])
+def test_gemm2_conv3x3(N, H, W, Cin, Cout, stride, pad, pad_hi, up):
+    ops = _ops()
+    x = rnd(N, H, W, Cin, seed=120).to(DEV)
+    w = rnd(Cout, Cin, 3, 3, seed=121, scale=(9 * Cin) ** -0.5)
+    b = rnd(Cout, seed=122).float()
+    out = ops.conv3x3(x, ops.pack_conv3x3(w).to(DEV), b.to(DEV), stride=stride, pad=pad, upsample=up, pad_hi=pad_hi)
+    ref = _conv_ref(x.cpu(), w, b, stride, pad, pad_hi, up)
+    close(out, ref, f"gemm2 conv3x3 {N}x{H}x{W} {Cin}->{Cout} s{stride} p{pad}/{pad_hi} up={up}")
+
+
+def test_gemm2_conv3x3_rowbias_residual():
+    ops = _ops()
+    N, H, W, Cin, Cout = 8, 64, 64, 64, 160
+    x = rnd(N, H, W, Cin, seed=123).to(DEV)
+    w = rnd(Cout, Cin, 3, 3, seed=124, scale=(9 * Cin) ** -0.5)
+    b = rnd(Cout, seed=125).float()
+    temb = rnd(2, Cout, seed=126).float()
+    res = rnd(N, H, W, Cout, seed=127).to(DEV)
+    out = ops.conv3x3(x, ops.pack_conv3x3(w).to(DEV), b.to(DEV), rowbias=temb.to(DEV), rows_per_group=4 * H * W,
+                      residual=res)
+    ref = _conv_ref(x.cpu(), w, b, 1, 1, 1, False) + temb.repeat_interleave(4, 0)[:, None, None, :] + res.float().cpu()
+    close(out, ref, "gemm2 conv3x3 + temb rowbias + residual")
+
+
+@pytest.mark.parametrize("M,C", [(4096, 320), (1000, 64), (777, 640), (50, 1280), (33, 2560), (200, 1408), (64, 8)])
+def test_layernorm_shapes(M, C):
+    ops = _ops()
+    x = rnd(M, C, seed=130, shift=0.3).to(DEV)
+    gamma = (1 + 0.1 * rnd(C, seed=131).float()).to(DEV)
+    beta = (0.1 * rnd(C, seed=132).float()).to(DEV)
+    out = ops.layernorm(x, gamma, beta)
+    close(out, F.layer_norm(x.float(), (C,), gamma, beta, 1e-5), f"layernorm {M}x{C}")
