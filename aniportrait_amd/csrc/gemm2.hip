@@ -22,7 +22,7 @@
 
 namespace {
 
-constexpr int BM2 = 256, BK2 = 32, NT2 = 512;
+constexpr int BK2 = 32;
 constexpr int RB = BK2 * 2;      // LDS row bytes
 constexpr int RPI = 1024 / RB;   // rows per LDS-DMA instruction (16)
 constexpr uint32_t OOB = 0xFFFFFFF0u;
@@ -31,13 +31,17 @@ constexpr uint32_t OOB = 0xFFFFFFF0u;
 
 __device__ __forceinline__ int swz_of(int row) { return ((row >> 3) & 1) * 2; }
 
-template <int BN, bool CONV>
-__global__ __launch_bounds__(NT2, 4) void gemm2_kernel(const anip_gemm_params p) {
+// BM2 = 256 (8 waves, 2 blocks per CU) for problems with >= ~1000 tiles, BM2 = 128 (4 waves, up to 3 blocks
+// per CU) to double the tile count of smaller problems.
+template <int BM2, int BN, bool CONV>
+__global__ __launch_bounds__(BM2 * 2, (BM2 == 256 ? 4 : 2)) void gemm2_kernel(const anip_gemm_params p) {
+  constexpr int NT2 = BM2 * 2;                 // threads: one wave per 32 tile rows
+  constexpr int NW = NT2 / 64;                 // waves, arranged (BM2/64) along M x 2 along N
   constexpr int NB = BN / 32;                  // 16-col MFMA tiles per wave along N
   constexpr int A_BYTES = BM2 * RB, B_BYTES = BN * RB, STAGE = A_BYTES + B_BYTES;
-  constexpr int NA_I = BM2 / RPI / 8;          // A DMA instructions per wave per K-tile (2)
+  constexpr int NA_I = BM2 / RPI / NW;         // A DMA instructions per wave per K-tile (2)
   constexpr int NB_TOT = BN / RPI;             // B DMA instructions per K-tile (8 or 10)
-  constexpr int NB_I = (NB_TOT + 7) / 8;       // max per wave (1 or 2)
+  constexpr int NB_I = (NB_TOT + NW - 1) / NW; // max per wave
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -97,13 +101,13 @@ __global__ __launch_bounds__(NT2, 4) void gemm2_kernel(const anip_gemm_params p)
   uint32_t b_off[NB_I];
 #pragma unroll
   for (int i = 0; i < NB_I; ++i) {
-    const int j = wave + 8 * i;
+    const int j = wave + NW * i;
     const int row = j * RPI + lr;
     const int g = ls ^ swz_of(row);
     const int n = n0 + row;
     b_off[i] = (j < NB_TOT && n < p.N) ? (uint32_t)(((int64_t)n * p.ldw + g * 8) * 2) : OOB;
   }
-  const int my_b = (NB_TOT - wave + 7) / 8;    // B DMA instructions this wave issues (wave-uniform: 1 or 2)
+  const int my_b = (NB_TOT - wave + NW - 1) / NW;  // B DMA instructions this wave issues (wave-uniform)
 
   auto issue = [&](int kt, int stage) {
     char* sa = smem + stage * STAGE;
@@ -140,10 +144,10 @@ __global__ __launch_bounds__(NT2, 4) void gemm2_kernel(const anip_gemm_params p)
       if (i < my_b) {
         uint32_t vo = b_off[i];
         if (ktail) {
-          const int row = (wave + 8 * i) * RPI + lr;
+          const int row = (wave + NW * i) * RPI + lr;
           if (k0 + (ls ^ swz_of(row)) * 8 >= p.K) vo = OOB;
         }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(sb + (wave + 8 * i) * 1024), 16, vo, (uint32_t)k0 * 2u, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(sb + (wave + NW * i) * 1024), 16, vo, (uint32_t)k0 * 2u, 0, 0);
       }
     }
   };
@@ -166,8 +170,8 @@ __global__ __launch_bounds__(NT2, 4) void gemm2_kernel(const anip_gemm_params p)
   for (int kt = 0; kt < nk; ++kt) {
     // this wave's part of tile kt has landed; leave only tile kt+1's DMA in flight
     if (kt + 1 < nk) {
-      if (my_b == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA_I + 2) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA_I + 1) : "memory");
+      if (my_b == NB_I) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA_I + NB_I) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA_I + NB_I - 1) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -187,13 +191,13 @@ __global__ __launch_bounds__(NT2, 4) void gemm2_kernel(const anip_gemm_params p)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
   }
 
-  // ---- epilogue: four passes of 64 rows through an fp32 LDS staging tile -----------------------------
+  // ---- epilogue: passes of 64 rows through an fp32 LDS staging tile ---------------------------------
   constexpr int CS = BN + 4;
   float* cs = (float*)smem;
   const float alpha = p.alpha;
   const bool geglu = p.act == 1;
   const int64_t obatch = (p.batch > 1) ? (int64_t)blockIdx.y * p.strideO : 0;
-  for (int pass = 0; pass < 4; ++pass) {
+  for (int pass = 0; pass < BM2 / 64; ++pass) {
     __builtin_amdgcn_s_barrier();  // readers of this LDS region (K loop / previous pass) are done
     if (wm == pass) {
 #pragma unroll
@@ -235,9 +239,10 @@ __global__ __launch_bounds__(NT2, 4) void gemm2_kernel(const anip_gemm_params p)
     } else if (geglu) {
       // packed columns per 128-tile: [64 x value | 64 x gate] -> 64 output columns
       if (BN == 128) {
-        const int cc = tid & 7, row = tid >> 3;
-        const int m = mbase + row;
+        const int cc = tid & 7;
         const int pn = n0 + cc * 8, ncol = bn * 64 + cc * 8;
+        for (int row = tid >> 3; row < 64; row += NT2 / 8) {
+        const int m = mbase + row;
         if (m < p.M && ncol < p.N / 2) {
           const float* hrow = cs + row * CS + cc * 8;
           const float* grow = hrow + 64;
@@ -254,6 +259,7 @@ __global__ __launch_bounds__(NT2, 4) void gemm2_kernel(const anip_gemm_params p)
 #pragma unroll
             for (int e = 0; e < 8; ++e) op[e] = t.e[e];
           }
+        }
         }
       }
     } else {
@@ -320,14 +326,15 @@ __global__ __launch_bounds__(NT2, 4) void gemm2_kernel(const anip_gemm_params p)
   }
 }
 
-template <int BN, bool CONV>
+template <int BM2, int BN, bool CONV>
 int launch_gemm2(const anip_gemm_params& p, hipStream_t stream) {
+  constexpr int NT2 = BM2 * 2;
   constexpr int STAGE = (BM2 + BN) * RB;
   constexpr int EPI = 64 * (BN + 4) * 4;
   constexpr int LDS = (3 * STAGE > EPI) ? 3 * STAGE : EPI;
   static bool attr_done = false;
   if (!attr_done) {
-    auto kfn = gemm2_kernel<BN, CONV>;
+    auto kfn = gemm2_kernel<BM2, BN, CONV>;
     if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
       anip_set_error("anip_gemm: cannot raise the dynamic LDS limit to %d bytes", LDS);
       return -2;
@@ -335,7 +342,7 @@ int launch_gemm2(const anip_gemm_params& p, hipStream_t stream) {
     attr_done = true;
   }
   const int nbm = (p.M + BM2 - 1) / BM2, nbn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm2_kernel<BN, CONV>), dim3((unsigned)(nbm * nbn), (unsigned)p.batch, 1), dim3(NT2), LDS, stream, p);
+  hipLaunchKernelGGL((gemm2_kernel<BM2, BN, CONV>), dim3((unsigned)(nbm * nbn), (unsigned)p.batch, 1), dim3(NT2), LDS, stream, p);
   return 1;
 }
 
@@ -355,9 +362,15 @@ int anip_gemm2_try(const anip_gemm_params& p, hipStream_t stream) {
     const int64_t pad128 = (int64_t)((p.N + 127) / 128) * 128, pad160 = (int64_t)((p.N + 159) / 160) * 160;
     if (pad160 < pad128) bn = 160;
   }
-  const int64_t tiles = (int64_t)((p.M + BM2 - 1) / BM2) * ((p.N + bn - 1) / bn) * (p.batch > 1 ? p.batch : 1);
-  if (tiles < 128) return 0;
+  const int64_t nb = p.batch > 1 ? p.batch : 1;
+  const int64_t tiles256 = (int64_t)((p.M + 255) / 256) * ((p.N + bn - 1) / bn) * nb;
+  if (tiles256 * 2 < 128) return 0;
   if (p.trans_out && (p.act == 1 || p.out_f32 || p.rowbias || p.residual)) return 0;
-  if (bn == 128) return p.conv ? launch_gemm2<128, true>(p, stream) : launch_gemm2<128, false>(p, stream);
-  return p.conv ? launch_gemm2<160, true>(p, stream) : launch_gemm2<160, false>(p, stream);
+  const bool big = tiles256 >= 1024;   // >= 2 full rounds of 2 x 256 resident 256-row blocks
+  if (big) {
+    if (bn == 128) return p.conv ? launch_gemm2<256, 128, true>(p, stream) : launch_gemm2<256, 128, false>(p, stream);
+    return p.conv ? launch_gemm2<256, 160, true>(p, stream) : launch_gemm2<256, 160, false>(p, stream);
+  }
+  if (bn == 128) return p.conv ? launch_gemm2<128, 128, true>(p, stream) : launch_gemm2<128, 128, false>(p, stream);
+  return p.conv ? launch_gemm2<128, 160, true>(p, stream) : launch_gemm2<128, 160, false>(p, stream);
 }
