@@ -9,7 +9,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libaniportrait_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -48,6 +48,11 @@ SIGNATURES = {
     "anip_gemm": (c_int, [C.POINTER(GemmParams), c_void_p]),
     "anip_conv_small": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                 c_int, c_void_p]),
+    "anip_conv_direct": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                 c_int, c_int, c_void_p]),
+    "anip_batchnorm_ws_floats": (c_int64, [c_int64, c_int]),
+    "anip_batchnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float,
+                               c_int, c_void_p, c_void_p]),
     "anip_ref_attention": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                    c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int,
                                    c_float, c_void_p]),
@@ -66,7 +71,7 @@ SIGNATURES = {
     "anip_profile_collect": (c_int, [c_int, C.POINTER(c_int64), C.POINTER(C.c_double)]),
     "anip_profile_kernel_name": (C.c_char_p, [c_int]),
 }
-N_KERNEL_IDS = 11  # ANIP_K_COUNT
+N_KERNEL_IDS = 12  # ANIP_K_COUNT
 
 _lib = None
 

@@ -53,7 +53,7 @@ std::vector<ProfRec> g_prof;
 const char* const kKernelNames[ANIP_K_COUNT] = {
     "gemm_kernel<false>", "gemm_kernel<true> (conv3x3)", "gn_stats_kernel", "gn_apply_kernel", "layernorm_kernel",
     "ref_attn_kernel", "temporal_attn_kernel", "softmax_rows_kernel", "conv_small_kernel", "linear_small_kernel",
-    "elementwise"};
+    "elementwise", "batchnorm_kernels"};
 }  // namespace
 
 void anip_prof_begin(int kid, hipStream_t s) {

@@ -357,9 +357,10 @@ extern "C" int anip_ref_attention(const void* q, int64_t ldq, const void* k, int
     case 40: launch_ref_attn<40>(a, Nf, s); break;
     case 64: launch_ref_attn<64>(a, Nf, s); break;
     case 80: launch_ref_attn<80>(a, Nf, s); break;
+    case 88: launch_ref_attn<88>(a, Nf, s); break;  // PoseGuider self-attention (16 heads x 88, pose_guider.py:86-89)
     case 160: launch_ref_attn<160>(a, Nf, s); break;
     default:
-      anip_set_error("anip_ref_attention: unsupported head dim %d (have 8,16,32,40,64,80,160)", d);
+      anip_set_error("anip_ref_attention: unsupported head dim %d (have 8,16,32,40,64,80,88,160)", d);
       return -1;
   }
   ANIP_LAUNCH_CHECK("anip_ref_attention");

@@ -82,6 +82,19 @@ class PackedNet:
             self.t[k] = self._raw(name).to(self.device, F16).permute(0, 2, 3, 1).contiguous()
         return self.t[k]
 
+    def conv_direct(self, name):
+        """small-channel conv weight -> fp16 [k*k*Cin][Cout8] (LDS image of anip_conv_direct)."""
+        k = ("convd", name)
+        if k not in self.t:
+            self.t[k] = ops.pack_conv_direct(self._raw(name).to(self.device, F16))
+        return self.t[k]
+
+    def scaled_f32(self, name, scale):
+        k = ("sf32", name, float(scale))
+        if k not in self.t:
+            self.t[k] = (self._raw(name).to(self.device, F32) * float(scale)).contiguous()
+        return self.t[k]
+
     def cat_lin(self, names):
         k = ("cat",) + tuple(names)
         if k not in self.t:
@@ -467,3 +480,61 @@ def vae_encode_mean(net, cfg, x):
     lat2 = m.shape[-1]
     q = ops.gemm(m.reshape(N * H * W, lat2), net.lin("quant_conv.weight"), net.f32("quant_conv.bias"))
     return q.reshape(N, H, W, lat2)[..., : cfg["latent_channels"]].contiguous()
+
+
+# ----------------------------------------------------------------------------------------------------
+# PoseGuider (src/models/pose_guider.py:13-162)
+# ----------------------------------------------------------------------------------------------------
+
+def _pose_conv_bn_relu(net, name, k, x, co, ks, stride, pad, training):
+    """Conv2d -> BatchNorm2d -> ReLU (entries 3k, 3k+1, 3k+2 of an nn.Sequential, pose_guider.py:19-85)."""
+    N, H, W, ci = x.shape
+    wn, bn_ = f"{name}.{3 * k}.weight", f"{name}.{3 * k}.bias"
+    if ks == 3 and ci % 32 == 0:
+        y = ops.conv3x3(x, net.conv3(wn), net.f32(bn_), stride=stride, pad=pad)       # MFMA implicit GEMM
+    else:
+        y = ops.conv_direct(x, net.conv_direct(wn), net.f32(bn_), co, ks, stride, pad)  # small-channel stem
+    n = f"{name}.{3 * k + 1}"
+    rm = rv = None
+    if not training:
+        rm, rv = net.f32(n + ".running_mean"), net.f32(n + ".running_var")
+    Nn, Ho, Wo, _ = y.shape
+    return ops.batchnorm(y.reshape(Nn * Ho * Wo, co), net.f32(n + ".weight"), net.f32(n + ".bias"), rm, rv, 1e-5,
+                         True).reshape(Nn, Ho, Wo, co)
+
+
+def _pose_self_attn(net, p, x, heads=16):
+    """pose_guider.Transformer2DModel (pose_guider.py:165-308) with cross_attention_dim=None: GroupNorm(1e-6) ->
+    1x1 proj_in -> [LN, 16-head self-attention (d = 88), +res, LN, GEGLU FF, +res] -> 1x1 proj_out -> +residual.
+    Its second argument (ref_x) never reaches the arithmetic (no attn2), so it is not evaluated."""
+    N, H, W, C = x.shape
+    T = H * W
+    h = ops.groupnorm(x.reshape(N, T, C), net.f32(p + ".norm.weight"), net.f32(p + ".norm.bias"), 32, 1e-6, False)
+    h = ops.gemm(h.reshape(N * T, C), net.lin(p + ".proj_in.weight"), net.f32(p + ".proj_in.bias"))
+    h = transformer_block(net, p + ".transformer_blocks.0", h, N, T, heads, None, 0)
+    out = ops.gemm(h, net.lin(p + ".proj_out.weight"), net.f32(p + ".proj_out.bias"), residual=x.reshape(N * T, C))
+    return out.reshape(N, H, W, C)
+
+
+def pose_guider_forward(net, stacks, x, training, use_ca):
+    """PoseGuider.forward (src/models/pose_guider.py:124-162) on channels-last frames.
+    x (N, H, W, 3) fp16 -> 5 feature maps (N, h, w, C) at 1/8, 1/16, 1/32, 1/64, 1/64 resolution."""
+    def stack(name, x):
+        _cin, layers = stacks[name]
+        for k, (co, ks, stride, pad) in enumerate(layers):
+            x = _pose_conv_bn_relu(net, name, k, x, co, ks, stride, pad, training)
+        return x
+
+    x = stack("conv_layers", x)
+    N, H, W, C = x.shape
+    scale = float(net.sd["scale"].detach().float().reshape(-1)[0])
+    # final_proj(x) * scale  ==  scale * (x W^T) + scale * b   (pose_guider.py:129-131)
+    x = ops.gemm(x.reshape(N * H * W, C), net.lin("final_proj.weight"), net.scaled_f32("final_proj.bias", scale),
+                 alpha=scale).reshape(N, H, W, -1)
+    fea = [x]
+    for i in range(1, 5):
+        x = stack(f"conv_layers_{i}", x)
+        if use_ca:
+            x = _pose_self_attn(net, f"cross_attn{i}", x)
+        fea.append(x)
+    return fea

@@ -37,6 +37,7 @@ def _req(t, dtype, name):
 # per-kernel profiling (HIP events in the library + algorithmic work counted here)
 # ------------------------------------------------------------------------------------------------
 K_GEMM, K_CONV3X3, K_GN_STATS, K_GN_APPLY, K_LAYERNORM, K_REF_ATTN, K_TEMPORAL_ATTN, K_SOFTMAX = range(8)
+K_CONV_SMALL, K_BATCHNORM = 8, 11
 _WORK = None  # kernel id -> algorithmic work (flops for 0,1,5; bytes otherwise) while profiling
 
 
@@ -258,6 +259,46 @@ def conv_small(x, w, bias, ksize, residual=None):
     y = torch.empty((N, H, Wd, Cout), dtype=F16, device=x.device)
     L.check(lib.anip_conv_small(_p(x), _p(w), _p(bias), _p(residual), _p(y), N, H, Wd, Cin, Cout, ksize, _stream()),
             "anip_conv_small")
+    return y
+
+
+def pack_conv_direct(w):
+    """torch conv weight [Cout, Cin, k, k] -> [k*k*Cin, Cout8] (tap-major, output channel fastest, Cout padded
+    with zeros to a multiple of 8): the LDS image of anip_conv_direct."""
+    co, ci, kh, kw = w.shape
+    co8 = (co + 7) // 8 * 8
+    wp = torch.zeros((kh * kw * ci, co8), dtype=w.dtype, device=w.device)
+    wp[:, :co] = w.permute(2, 3, 1, 0).reshape(kh * kw * ci, co)
+    return wp.contiguous()
+
+
+def conv_direct(x, wp, bias, Cout, ksize, stride=1, pad=1, relu=False):
+    """x (N, H, W, Cin) fp16, wp from pack_conv_direct -> (N, Ho, Wo, Cout) fp16."""
+    lib = L.load()
+    _req(x, F16, "x")
+    _req(wp, F16, "wp")
+    N, H, Wd, Cin = x.shape
+    assert wp.shape[0] == ksize * ksize * Cin and wp.shape[1] == (Cout + 7) // 8 * 8
+    Ho = (H + 2 * pad - ksize) // stride + 1
+    Wo = (Wd + 2 * pad - ksize) // stride + 1
+    y = torch.empty((N, Ho, Wo, Cout), dtype=F16, device=x.device)
+    _work(K_CONV_SMALL, x.numel() * 2 + y.numel() * 2)
+    L.check(lib.anip_conv_direct(_p(x), _p(wp), _p(bias), _p(y), N, H, Wd, Cin, Cout, ksize, stride, pad,
+                                 int(bool(relu)), _stream()), "anip_conv_direct")
+    return y
+
+
+def batchnorm(x, gamma, beta, running_mean=None, running_var=None, eps=1e-5, relu=True):
+    """x (M, C) fp16 channels-last rows -> relu?(BatchNorm(x)); batch statistics unless running stats are given."""
+    lib = L.load()
+    _req(x, F16, "x")
+    M, Cc = x.shape
+    y = torch.empty_like(x)
+    ws = torch.empty((lib.anip_batchnorm_ws_floats(M, Cc),), dtype=F32, device=x.device)
+    _work(K_BATCHNORM, M * Cc * (6 if running_mean is None else 4))
+    L.check(lib.anip_batchnorm(_p(x), _p(_req(gamma, F32, "gamma")), _p(_req(beta, F32, "beta")), _p(running_mean),
+                               _p(running_var), _p(y), M, Cc, float(eps), int(bool(relu)), _p(ws), _stream()),
+            "anip_batchnorm")
     return y
 
 

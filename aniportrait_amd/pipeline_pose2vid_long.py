@@ -280,12 +280,10 @@ class Pose2VideoPipeline:
         def pose_features(k):
             if k not in pose_cache:
                 c = windows[k]
-                fea = pg(pose[:, :, c], ref_pose)                    # batch 1: CFG duplication does not change
-                out = []                                             # train-mode BatchNorm statistics
-                for t_ in fea:
-                    n = ops.ncfhw_to_nhwc(t_.contiguous())
-                    out.append(n.repeat(S, 1, 1, 1).contiguous() if S > 1 else n)
-                pose_cache[k] = out
+                # batch 1: the CFG duplication does not change train-mode BatchNorm statistics; ref_pose never
+                # reaches the arithmetic (pose_guider.py: cross_attention_dim=None => no attn2)
+                fea = pg.forward_nhwc(ops.ncfhw_to_nhwc(pose[:, :, c].contiguous()))
+                pose_cache[k] = [n.repeat(S, 1, 1, 1).contiguous() if S > 1 else n for n in fea]
             return pose_cache[k]
 
         acc = torch.empty((S, L, HWC), dtype=torch.float32, device=device)

@@ -1,7 +1,10 @@
-"""`PoseGuider` (src/models/pose_guider.py:13-162) — ADJACENT to the hot path: it
-stays plain PyTorch (rocm torch conv / linear / SDPA), is independent of the DDIM timestep and is
-therefore evaluated once per context window by the pipeline instead of once per step
-(src/pipelines/pipeline_pose2vid_long.py:531-536 recomputes it every step).
+"""`PoseGuider` (src/models/pose_guider.py:13-162) — SURVEY.md §8f rank 1: independent of the DDIM timestep,
+so the pipeline evaluates it once per context window instead of once per step
+(src/pipelines/pipeline_pose2vid_long.py:531-536 recomputes it every step).  On the GPU it runs on the HIP
+engine (`engine.pose_guider_forward`: direct / implicit-GEMM convolutions, BatchNorm+ReLU, the four
+self-attention blocks on the MFMA GEMM and attention kernels) — stock torch convs in fp16 fall into MIOpen's
+`naive_conv_*` kernels here (0.8 s per 512x512 clip).  CPU tensors take the plain-PyTorch restatement below
+(the reference keeps this module in torch; it is what the CPU tests and the oracle comparison use).
 
 Same constructor, state-dict names (incl. BatchNorm buffers) and forward signature as the reference.
 Quirks kept on purpose:
@@ -16,6 +19,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import _lib
 from .params import build_tree, pose_guider_shapes, pose_guider_stacks
 
 
@@ -27,6 +31,7 @@ class PoseGuider(nn.Module):
         params, buffers = pose_guider_shapes(noise_latent_channels, use_ca)
         build_tree(self, params, buffers)
         self._stacks = pose_guider_stacks(noise_latent_channels)
+        object.__setattr__(self, "_packed", None)
         with torch.no_grad():
             self.scale.fill_(2.0)
             self.final_proj.weight.zero_()  # reference init (:119-122); checkpoints overwrite it
@@ -48,6 +53,28 @@ class PoseGuider(nn.Module):
         model = cls(noise_latent_channels=320)
         model.load_state_dict(state_dict, strict=True)
         return model
+
+    # -- packed weights for the HIP engine (rebuilt lazily whenever the parameters change) ----------------
+    def _apply(self, fn, *a, **k):
+        object.__setattr__(self, "_packed", None)
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        object.__setattr__(self, "_packed", None)
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
+    def packed(self):
+        from .engine import PackedNet
+        _lib.load()
+        if self._packed is None or self._packed.device != self.device:
+            object.__setattr__(self, "_packed", PackedNet(self.state_dict(), self.device))
+        return self._packed
+
+    @torch.no_grad()
+    def forward_nhwc(self, x):
+        """x (N, H, W, 3) fp16 on the GPU -> 5 channels-last feature maps (N, h, w, C) (HIP engine)."""
+        from . import engine
+        return engine.pose_guider_forward(self.packed(), self._stacks, x, self.training, self.use_ca)
 
     # ------------------------------------------------------------------------------------------------
     def _p(self, name):
@@ -94,6 +121,10 @@ class PoseGuider(nn.Module):
     def forward(self, x, ref_x=None):
         """x (b, 3, f, H, W) -> 5 feature maps (b, C, f, h, w) at 1/8, 1/16, 1/32, 1/64, 1/64 resolution."""
         b, c, f, H, W = x.shape
+        if x.is_cuda:
+            from . import hipops as ops
+            return [ops.nhwc_to_ncfhw(t, b, out_f32=(x.dtype == torch.float32))
+                    for t in self.forward_nhwc(ops.ncfhw_to_nhwc(x))]
         x = x.permute(0, 2, 1, 3, 4).reshape(b * f, c, H, W)
 
         def out(t):

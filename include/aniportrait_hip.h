@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ANIP_ABI_VERSION 2
+#define ANIP_ABI_VERSION 3
 
 int anip_version(void);
 const char* anip_last_error(void);
@@ -89,6 +89,22 @@ int anip_gemm(const anip_gemm_params* p, void* stream);
  * (pose feature add, unet_3d.py:485-486), y fp16.  ksize 1 or 3, stride 1, pad ksize/2. */
 int anip_conv_small(const void* x, const void* w, const float* bias, const void* residual, void* y,
                     int N, int H, int W, int Cin, int Cout, int ksize, void* stream);
+
+/* ---- PoseGuider stem: direct convolution + BatchNorm2d(+ReLU) --------------------------------------
+ * replaces the nn.Conv2d / nn.BatchNorm2d / nn.ReLU stacks of src/models/pose_guider.py:19-85 whose channel
+ * counts (3, 16, 32) or 4x4-stride-2 windows do not fit the implicit-GEMM kernel.
+ * anip_conv_direct: x [N,H,W,Cin] fp16; wp [ksize*ksize*Cin][Cout8] fp16 with Cout8 = Cout rounded up to 8
+ * (tap-major, output channel fastest, zero padded); bias fp32 [Cout] or NULL; y [N,Ho,Wo,Cout] fp16,
+ * Ho = (H + 2 pad - ksize) / stride + 1.  ksize 1..5, stride 1 or 2; ksize*ksize*Cin*Cout8*2 <= 64 KB.
+ * anip_batchnorm: x,y [M][C] fp16 (channels-last rows = N*H*W); running_mean/var NULL -> batch statistics
+ * with biased variance (module in training mode: scripts/pose2vid.py:77 never calls .eval()), else the
+ * running statistics.  ws: fp32 workspace of anip_batchnorm_ws_floats(M, C) elements. */
+int anip_conv_direct(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Cin,
+                     int Cout, int ksize, int stride, int pad, int relu, void* stream);
+int64_t anip_batchnorm_ws_floats(int64_t M, int C);
+int anip_batchnorm(const void* x, const float* gamma, const float* beta, const float* running_mean,
+                   const float* running_var, void* y, int64_t M, int C, float eps, int relu, float* ws,
+                   void* stream);
 
 /* ---- reference attention (spatial) ---------------------------------------------------------------
  * replaces attn1 of the hacked TemporalBasicTransformerBlock in read mode
@@ -154,7 +170,8 @@ enum {
   ANIP_K_CONV_SMALL = 8,
   ANIP_K_LINEAR_SMALL = 9,
   ANIP_K_ELEMENTWISE = 10, /* add / window accumulate / cfg+ddim / layout conversions */
-  ANIP_K_COUNT = 11
+  ANIP_K_BATCHNORM = 11,  /* bn_stats + bn_finalize + bn_apply (PoseGuider) */
+  ANIP_K_COUNT = 12
 };
 int anip_profile_enable(int on);
 int anip_profile_collect(int max_ids, int64_t* launches, double* total_ms);

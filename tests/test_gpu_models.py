@@ -67,6 +67,40 @@ def test_refnet_banks_and_unet3d_match_reference(setup):
 
 
 @torch.no_grad()
+def test_pose_guider_matches_reference(setup):
+    """PoseGuider on the HIP engine (direct / MFMA convs, train-mode BatchNorm, 16 x 88 self-attention blocks) vs
+    the reference module's own fp32 output (small: golden from /root/reference) or the CPU oracle (real width)."""
+    from golden_inputs import unet_case
+    m, gold, small = setup["m"], setup["gold"], setup["small"]
+    c = unet_case(small)
+    pg = m["pose_guider"]
+    assert pg.training  # the reference scripts never call .eval(): batch statistics
+    fea = pg(c["pose"].to(DEV, torch.float16), c["ref_pose"].to(DEV, torch.float16))
+    if small:
+        want = [gold[f"pose_fea/{i}"] for i in range(5)]
+    else:
+        from oracle import ref_torch as O
+        want = O.pose_guider(setup["sds"]["pose_guider"], c["pose"], c["ref_pose"])
+    assert len(fea) == 5
+    for i, (f_, w_) in enumerate(zip(fea, want)):
+        assert f_.shape == w_.shape and f_.dtype == torch.float16
+        e = rel_err(f_.float().cpu(), w_.float())
+        print(f"pose_fea[{i}] {tuple(f_.shape)} rel_max_err={e:.3e}")
+        assert e < TOL, (i, e)
+    # fp32 in -> fp32 out; eval mode uses the running statistics (mean 0 / var 1 buffers) and differs
+    f32 = pg(c["pose"].to(DEV), c["ref_pose"].to(DEV))
+    assert f32[0].dtype == torch.float32 and torch.equal(f32[0].half(), fea[0])
+    pg.eval()
+    try:
+        ev = pg(c["pose"].to(DEV, torch.float16), None)
+        ev_ref = pg.float().cpu()(c["pose"], None)
+        assert rel_err(ev[0].float().cpu(), ev_ref[0]) < TOL
+    finally:
+        pg.train()
+        m["pose_guider"] = pg.to(DEV, torch.float16)
+
+
+@torch.no_grad()
 def test_vae_matches_reference(setup):
     from golden_inputs import vae_case
     m, gold = setup["m"], setup["gold"]

@@ -238,7 +238,7 @@ def _attn_ref(q, k, v, scale):
     return torch.einsum("hqk,hkd->hqd", torch.softmax(s, -1), v)
 
 
-@pytest.mark.parametrize("d", [8, 16, 32, 40, 64, 80, 160])
+@pytest.mark.parametrize("d", [8, 16, 32, 40, 64, 80, 88, 160])
 @pytest.mark.parametrize("T", [4, 16, 100, 256])
 def test_ref_attention(d, T):
     ops = _ops()
@@ -459,3 +459,52 @@ def test_layernorm_shapes(M, C):
     beta = (0.1 * rnd(C, seed=132).float()).to(DEV)
     out = ops.layernorm(x, gamma, beta)
     close(out, F.layer_norm(x.float(), (C,), gamma, beta, 1e-5), f"layernorm {M}x{C}")
+
+
+# ------------------------------------------------------------------------------------------------
+# PoseGuider stem kernels: direct convolution, BatchNorm2d(+ReLU)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,H,W,Cin,Cout,ks,stride,pad", [
+    (2, 32, 32, 3, 3, 3, 1, 1), (2, 32, 32, 3, 16, 4, 2, 1), (1, 17, 23, 16, 16, 3, 1, 1), (2, 16, 16, 16, 32, 4, 2, 1),
+    (1, 20, 12, 32, 64, 4, 2, 1), (3, 9, 9, 8, 24, 3, 2, 1), (1, 8, 8, 5, 7, 1, 1, 0), (4, 128, 128, 3, 16, 4, 2, 1)])
+def test_conv_direct(N, H, W, Cin, Cout, ks, stride, pad):
+    ops = _ops()
+    x = rnd(N, H, W, Cin, seed=1).to(DEV)
+    w = rnd(Cout, Cin, ks, ks, seed=2, scale=(Cin * ks * ks) ** -0.5)
+    b = rnd(Cout, seed=3).float()
+    for relu in (False, True):
+        y = ops.conv_direct(x, ops.pack_conv_direct(w.to(DEV)), b.to(DEV), Cout, ks, stride, pad, relu=relu)
+        ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.float(), b, stride=stride, padding=pad)
+        if relu:
+            ref = F.relu(ref)
+        close(y, ref.permute(0, 2, 3, 1), f"conv_direct {Cin}->{Cout} k{ks} s{stride} relu={relu}")
+
+
+@pytest.mark.parametrize("M,C", [(4 * 64 * 64, 3), (1000, 16), (33, 64), (70000, 128), (4096, 320), (300, 1280),
+                                 (129, 5), (8, 8)])
+@pytest.mark.parametrize("train", [True, False])
+def test_batchnorm(M, C, train):
+    ops = _ops()
+    x = rnd(M, C, seed=4, scale=3.0, shift=1.5)
+    g = (1 + 0.2 * rnd(C, seed=5).float())
+    b = 0.3 * rnd(C, seed=6).float()
+    rm, rv = 0.5 * rnd(C, seed=7).float(), (1 + 0.5 * rnd(C, seed=8).float().abs())
+    for relu in (True, False):
+        y = ops.batchnorm(x.to(DEV), g.to(DEV), b.to(DEV), None if train else rm.to(DEV), None if train else rv.to(DEV),
+                          1e-5, relu)
+        ref = F.batch_norm(x.float(), None if train else rm.clone(), None if train else rv.clone(), g, b,
+                           training=train, eps=1e-5)
+        if relu:
+            ref = F.relu(ref)
+        close(y, ref, f"batchnorm M={M} C={C} train={train} relu={relu}")
+
+
+def test_batchnorm_large_offset():
+    """values like the pose images' [-1, 509] range after the first conv: mean >> std must not cancel"""
+    ops = _ops()
+    M, C = 50000, 16
+    x = rnd(M, C, seed=9, scale=2.0, shift=300.0)
+    g, b = torch.ones(C), torch.zeros(C)
+    y = ops.batchnorm(x.to(DEV), g.to(DEV), b.to(DEV), None, None, 1e-5, False)
+    ref = F.batch_norm(x.double(), None, None, g.double(), b.double(), training=True, eps=1e-5)
+    close(y, ref, "batchnorm offset", rtol=4e-3, arms=4e-3)
