@@ -69,6 +69,8 @@ SIGNATURES = {
                                    c_void_p]),
     "anip_profile_enable": (c_int, [c_int]),
     "anip_profile_collect": (c_int, [c_int, C.POINTER(c_int64), C.POINTER(C.c_double)]),
+    "anip_profile_collect_records": (c_int, [c_int, C.POINTER(c_int64), C.POINTER(C.c_double), c_int64,
+                                             C.POINTER(c_int), C.POINTER(c_float), C.POINTER(c_int64)]),
     "anip_profile_kernel_name": (C.c_char_p, [c_int]),
 }
 N_KERNEL_IDS = 12  # ANIP_K_COUNT

@@ -77,11 +77,17 @@ extern "C" int anip_profile_enable(int on) {
 }
 
 extern "C" int anip_profile_collect(int max_ids, int64_t* launches, double* total_ms) {
+  return anip_profile_collect_records(max_ids, launches, total_ms, 0, nullptr, nullptr, nullptr);
+}
+
+extern "C" int anip_profile_collect_records(int max_ids, int64_t* launches, double* total_ms, int64_t max_records,
+                                            int* rec_kid, float* rec_ms, int64_t* n_records) {
   for (int i = 0; i < max_ids; ++i) {
     launches[i] = 0;
     total_ms[i] = 0.0;
   }
   int rc = 0;
+  int64_t nrec = 0;
   for (ProfRec& r : g_prof) {
     float ms = 0.f;
     hipError_t e = hipEventSynchronize(r.b);
@@ -93,9 +99,15 @@ extern "C" int anip_profile_collect(int max_ids, int64_t* launches, double* tota
       launches[r.kid] += 1;
       total_ms[r.kid] += (double)ms;
     }
+    if (nrec < max_records && rec_kid != nullptr && rec_ms != nullptr) {
+      rec_kid[nrec] = r.kid;
+      rec_ms[nrec] = (e == hipSuccess) ? ms : -1.f;
+    }
+    ++nrec;
     (void)hipEventDestroy(r.a);
     (void)hipEventDestroy(r.b);
   }
+  if (n_records != nullptr) *n_records = nrec;
   g_prof.clear();
   return rc;
 }

@@ -490,7 +490,7 @@ def _pose_conv_bn_relu(net, name, k, x, co, ks, stride, pad, training):
     """Conv2d -> BatchNorm2d -> ReLU (entries 3k, 3k+1, 3k+2 of an nn.Sequential, pose_guider.py:19-85)."""
     N, H, W, ci = x.shape
     wn, bn_ = f"{name}.{3 * k}.weight", f"{name}.{3 * k}.bias"
-    if ks == 3 and ci % 32 == 0:
+    if ks == 3 and ci % 64 == 0:
         y = ops.conv3x3(x, net.conv3(wn), net.f32(bn_), stride=stride, pad=pad)       # MFMA implicit GEMM
     else:
         y = ops.conv_direct(x, net.conv_direct(wn), net.f32(bn_), co, ks, stride, pad)  # small-channel stem

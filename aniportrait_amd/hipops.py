@@ -37,52 +37,76 @@ def _req(t, dtype, name):
 # per-kernel profiling (HIP events in the library + algorithmic work counted here)
 # ------------------------------------------------------------------------------------------------
 K_GEMM, K_CONV3X3, K_GN_STATS, K_GN_APPLY, K_LAYERNORM, K_REF_ATTN, K_TEMPORAL_ATTN, K_SOFTMAX = range(8)
-K_CONV_SMALL, K_BATCHNORM = 8, 11
+K_CONV_SMALL, K_LINEAR_SMALL, K_ELEMENTWISE, K_BATCHNORM = 8, 9, 10, 11
+_FLOP_KERNELS = (K_GEMM, K_CONV3X3, K_REF_ATTN)
 _WORK = None  # kernel id -> algorithmic work (flops for 0,1,5; bytes otherwise) while profiling
+_CALLS = None  # [(kernel id, shape descriptor, work)] in launch order while profiling
 
 
-def _work(kid, amount):
+def _work(kid, amount, desc=""):
+    """one call per library-side event bracket, in launch order (profile() pairs them up by position)"""
     if _WORK is not None:
         _WORK[kid] = _WORK.get(kid, 0) + amount
+        _CALLS.append((kid, desc, amount))
 
 
 class profile:
     """`with profile() as p: ...; p.result` -> {kernel name: {launches, ms, work, unit, rate}}.
     Every kernel launch inside the block is bracketed by HIP events on its stream (library side);
-    `work` is the algorithmic FLOP (contractions) or byte (HBM-bound kernels) count of those launches."""
+    `work` is the algorithmic FLOP (contractions) or byte (HBM-bound kernels) count of those launches.
+    `p.by_shape`: the same, keyed by (kernel name, shape descriptor), when the per-launch records line up
+    with the wrapper calls."""
 
     def __enter__(self):
-        global _WORK
+        global _WORK, _CALLS
         lib = L.load()
         torch.cuda.synchronize()
         lib.anip_profile_collect(0, None, None)  # drop stale records
         lib.anip_profile_enable(1)
-        _WORK = {}
+        _WORK, _CALLS = {}, []
         self.result = None
+        self.by_shape = None
         return self
 
     def __exit__(self, *exc):
-        global _WORK
+        global _WORK, _CALLS
         lib = L.load()
         lib.anip_profile_enable(0)
         n = L.N_KERNEL_IDS
         launches = (C.c_int64 * n)()
         ms = (C.c_double * n)()
-        rc = lib.anip_profile_collect(n, launches, ms)
-        work, _WORK = _WORK, None
+        work, calls = _WORK, _CALLS
+        _WORK = _CALLS = None
+        cap = len(calls) + 16
+        rk = (C.c_int * cap)()
+        rms = (C.c_float * cap)()
+        nrec = C.c_int64(0)
+        rc = lib.anip_profile_collect_records(n, launches, ms, cap, rk, rms, C.byref(nrec))
         if exc[0] is None:
-            L.check(rc, "anip_profile_collect")
+            L.check(rc, "anip_profile_collect_records")
         res = {}
         for k in range(n):
             if launches[k] == 0:
                 continue
-            flops = k in (K_GEMM, K_CONV3X3, K_REF_ATTN)
+            flops = k in _FLOP_KERNELS
             w = work.get(k, 0)
             t = ms[k] * 1e-3
             res[lib.anip_profile_kernel_name(k).decode()] = dict(
                 id=k, launches=int(launches[k]), ms=ms[k], work=w, unit="TFLOP/s" if flops else "GB/s",
                 rate=(w / t / (1e12 if flops else 1e9)) if t > 0 else 0.0)
         self.result = res
+        if nrec.value == len(calls) and all(rk[i] == calls[i][0] for i in range(len(calls))):
+            agg = {}
+            for i, (k, desc, w) in enumerate(calls):
+                a = agg.setdefault((k, desc), [0, 0.0, 0])
+                a[0] += 1
+                a[1] += float(rms[i])
+                a[2] += w
+            self.by_shape = [
+                dict(kernel=lib.anip_profile_kernel_name(k).decode(), shape=desc, launches=c, ms=t, work=w,
+                     unit="TFLOP/s" if k in _FLOP_KERNELS else "GB/s",
+                     rate=(w / (t * 1e-3) / (1e12 if k in _FLOP_KERNELS else 1e9)) if t > 0 else 0.0)
+                for (k, desc), (c, t, w) in sorted(agg.items(), key=lambda kv: -kv[1][1])]
         return False
 
 
@@ -134,8 +158,8 @@ def groupnorm(x1, gamma, beta, groups, eps, silu, x2=None):
     Ctot = C1 + C2
     y = torch.empty((N, HW, Ctot), dtype=F16, device=x1.device)
     ws = torch.empty((lib.anip_groupnorm_ws_floats(N, HW, Ctot, groups),), dtype=F32, device=x1.device)
-    _work(K_GN_STATS, N * HW * Ctot * 2)
-    _work(K_GN_APPLY, N * HW * Ctot * 4)
+    _work(K_GN_STATS, N * HW * Ctot * 2, f"N{N} HW{HW} C{Ctot}")
+    _work(K_GN_APPLY, N * HW * Ctot * 4, f"N{N} HW{HW} C{Ctot} silu{int(bool(silu))}")
     L.check(lib.anip_groupnorm(_p(x1), C1, _p(x2), C2, _p(_req(gamma, F32, "gamma")), _p(_req(beta, F32, "beta")),
                                _p(y), N, HW, groups, float(eps), int(bool(silu)), _p(ws), _stream()),
             "anip_groupnorm")
@@ -147,7 +171,7 @@ def layernorm(x, gamma, beta, eps=1e-5, pe=None, rows_per_frame=0, frames=0):
     _req(x, F16, "x")
     M, Cc = x.shape
     y = torch.empty_like(x)
-    _work(K_LAYERNORM, M * Cc * 4)
+    _work(K_LAYERNORM, M * Cc * 4, f"M{M} C{Cc}")
     L.check(lib.anip_layernorm(_p(x), _p(_req(gamma, F32, "gamma")), _p(_req(beta, F32, "beta")), _p(y), M, Cc,
                                float(eps), _p(pe), int(rows_per_frame), int(frames), _stream()), "anip_layernorm")
     return y
@@ -227,7 +251,16 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
             raise TypeError("residual: expected fp16")
         p.residual, p.ldr = _p(residual), int(ldr if ldr is not None else n_out)
     p.act = int(act)
-    _work(K_CONV3X3 if conv is not None else K_GEMM, 2 * M * N * K * max(1, int(p.batch)))
+    if _WORK is not None:
+        if conv is not None:
+            desc = (f"N{conv['Nimg']} {conv['Hin']}x{conv['Win']} Cin{conv['Cin']} Cout{N} s{conv['stride']}"
+                    f"{' up' if conv.get('upsample') else ''}{' rb' if rowbias is not None else ''}"
+                    f"{' res' if residual is not None else ''}")
+        else:
+            desc = (f"M{M} N{N} K{K}{' b%d' % batch if batched else ''}{' geglu' if act == 1 else ''}"
+                    f"{' A2' if A2 is not None else ''}{' rb' if rowbias is not None else ''}"
+                    f"{' res' if residual is not None else ''}{' T' if trans_out else ''}{' f32' if out_f32 else ''}")
+        _work(K_CONV3X3 if conv is not None else K_GEMM, 2 * M * N * K * max(1, int(p.batch)), desc)
     L.check(lib.anip_gemm(C.byref(p), _stream()), "anip_gemm")
     return out
 
@@ -257,6 +290,7 @@ def conv_small(x, w, bias, ksize, residual=None):
     N, H, Wd, Cin = x.shape
     Cout = w.shape[0]
     y = torch.empty((N, H, Wd, Cout), dtype=F16, device=x.device)
+    _work(K_CONV_SMALL, x.numel() * 2 + y.numel() * 2, f"small N{N} {H}x{Wd} Cin{Cin} Cout{Cout} k{ksize}")
     L.check(lib.anip_conv_small(_p(x), _p(w), _p(bias), _p(residual), _p(y), N, H, Wd, Cin, Cout, ksize, _stream()),
             "anip_conv_small")
     return y
@@ -282,7 +316,7 @@ def conv_direct(x, wp, bias, Cout, ksize, stride=1, pad=1, relu=False):
     Ho = (H + 2 * pad - ksize) // stride + 1
     Wo = (Wd + 2 * pad - ksize) // stride + 1
     y = torch.empty((N, Ho, Wo, Cout), dtype=F16, device=x.device)
-    _work(K_CONV_SMALL, x.numel() * 2 + y.numel() * 2)
+    _work(K_CONV_SMALL, x.numel() * 2 + y.numel() * 2, f"direct N{N} {H}x{Wd} Cin{Cin} Cout{Cout} k{ksize} s{stride}")
     L.check(lib.anip_conv_direct(_p(x), _p(wp), _p(bias), _p(y), N, H, Wd, Cin, Cout, ksize, stride, pad,
                                  int(bool(relu)), _stream()), "anip_conv_direct")
     return y
@@ -295,7 +329,7 @@ def batchnorm(x, gamma, beta, running_mean=None, running_var=None, eps=1e-5, rel
     M, Cc = x.shape
     y = torch.empty_like(x)
     ws = torch.empty((lib.anip_batchnorm_ws_floats(M, Cc),), dtype=F32, device=x.device)
-    _work(K_BATCHNORM, M * Cc * (6 if running_mean is None else 4))
+    _work(K_BATCHNORM, M * Cc * (6 if running_mean is None else 4), f"M{M} C{Cc}")
     L.check(lib.anip_batchnorm(_p(x), _p(_req(gamma, F32, "gamma")), _p(_req(beta, F32, "beta")), _p(running_mean),
                                _p(running_var), _p(y), M, Cc, float(eps), int(bool(relu)), _p(ws), _stream()),
             "anip_batchnorm")
@@ -307,7 +341,8 @@ def ref_attention(q, ldq, k, ldk, vt, ldvt, n_frames, T, heads, d, kref=None, ld
     """see anip_ref_attention; returns (n_frames*T, heads*d) fp16.  `n_ref_frames` (frames whose
     ref_index >= 0) is only used for the profiler's FLOP count."""
     lib = L.load()
-    _work(K_REF_ATTN, 4 * T * T * heads * d * (n_frames + (n_ref_frames if ref_index is not None else 0)))
+    _work(K_REF_ATTN, 4 * T * T * heads * d * (n_frames + (n_ref_frames if ref_index is not None else 0)),
+          f"Nf{n_frames} T{T} h{heads} d{d} ref{n_ref_frames if ref_index is not None else 0}")
     out = torch.empty((n_frames * T, heads * d), dtype=F16, device=q.device)
     if scale is None:
         scale = d ** -0.5
@@ -323,7 +358,7 @@ def temporal_attention(qkv, B, F, T, heads, d, scale=None):
     out = torch.empty((B * F * T, heads * d), dtype=F16, device=qkv.device)
     if scale is None:
         scale = d ** -0.5
-    _work(K_TEMPORAL_ATTN, B * F * T * heads * d * 4 * 2)
+    _work(K_TEMPORAL_ATTN, B * F * T * heads * d * 4 * 2, f"B{B} F{F} T{T} h{heads} d{d}")
     L.check(lib.anip_temporal_attention(_p(qkv), _p(out), B, F, T, heads, d, float(scale), _stream()),
             "anip_temporal_attention")
     return out
@@ -334,7 +369,7 @@ def softmax_rows(s):
     _req(s, F32, "s")
     rows = s.numel() // s.shape[-1]
     p = torch.empty(s.shape, dtype=F16, device=s.device)
-    _work(K_SOFTMAX, s.numel() * 6)
+    _work(K_SOFTMAX, s.numel() * 6, f"rows{rows} cols{s.shape[-1]}")
     L.check(lib.anip_softmax_rows(_p(s), _p(p), rows, s.shape[-1], _stream()), "anip_softmax_rows")
     return p
 
@@ -347,6 +382,7 @@ def linear_small(x, W, bias=None, silu_in=False):
     M, K = x.shape
     N = W.shape[0]
     y = torch.empty((M, N), dtype=F32, device=x.device)
+    _work(K_LINEAR_SMALL, N * K * 2, f"M{M} N{N} K{K}")
     L.check(lib.anip_linear_small(_p(x), _p(W), _p(bias), _p(y), M, N, K, int(bool(silu_in)), _stream()),
             "anip_linear_small")
     return y
@@ -357,18 +393,21 @@ def add(a, b):
     _req(a, F16, "a")
     _req(b, F16, "b")
     out = torch.empty_like(a)
+    _work(K_ELEMENTWISE, a.numel() * 6, "add")
     L.check(lib.anip_add(_p(a), _p(b), _p(out), a.numel(), _stream()), "anip_add")
     return out
 
 
 def window_accumulate(pred, acc, counter, frames, S, Fw, L_, HWC):
     lib = L.load()
+    _work(K_ELEMENTWISE, S * Fw * HWC * 10, "window_accumulate")
     L.check(lib.anip_window_accumulate(_p(pred), _p(acc), _p(counter), _p(frames), S, Fw, L_, HWC, _stream()),
             "anip_window_accumulate")
 
 
 def cfg_ddim_step(acc, counter, latents, latents_f16, S, L_, HWC, guidance, sa, sb, sap, sbp):
     lib = L.load()
+    _work(K_ELEMENTWISE, L_ * HWC * (4 * S + 10), "cfg_ddim_step")
     L.check(lib.anip_cfg_ddim_step(_p(acc), _p(counter), _p(latents), _p(latents_f16), S, L_, HWC, float(guidance),
                                    float(sa), float(sb), float(sap), float(sbp), _stream()), "anip_cfg_ddim_step")
 
@@ -381,6 +420,7 @@ def ncfhw_to_nhwc(src):
     src = src.contiguous()
     B, Cc, Fr, H, Wd = src.shape
     dst = torch.empty((B * Fr, H, Wd, Cc), dtype=F16, device=src.device)
+    _work(K_ELEMENTWISE, src.numel() * (src.element_size() + 2), "ncfhw_to_nhwc")
     L.check(lib.anip_ncfhw_to_nhwc(_p(src), int(src.dtype == F32), _p(dst), B, Cc, Fr, H * Wd, _stream()),
             "anip_ncfhw_to_nhwc")
     return dst
@@ -393,6 +433,7 @@ def nhwc_to_ncfhw(src, B, out_f32=False, scale=1.0, shift=0.0, clamp01=False):
     BF, H, Wd, Cc = src.shape
     Fr = BF // B
     dst = torch.empty((B, Cc, Fr, H, Wd), dtype=F32 if out_f32 else F16, device=src.device)
+    _work(K_ELEMENTWISE, src.numel() * (2 + dst.element_size()), "nhwc_to_ncfhw")
     L.check(lib.anip_nhwc_to_ncfhw(_p(src), _p(dst), int(out_f32), B, Cc, Fr, H * Wd, float(scale), float(shift),
                                    int(bool(clamp01)), _stream()), "anip_nhwc_to_ncfhw")
     return dst

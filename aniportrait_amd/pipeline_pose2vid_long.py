@@ -204,14 +204,18 @@ class Pose2VideoPipeline:
         a_p = float(sch.alphas_cumprod[prev]) if prev >= 0 else float(sch.final_alpha_cumprod)
         return math.sqrt(a_t), math.sqrt(max(1 - a_t, 0.0)), math.sqrt(a_p), math.sqrt(max(1 - a_p, 0.0))
 
+    @staticmethod
+    def _require_gpu(device):
+        if device.type != "cuda":
+            raise RuntimeError("Pose2VideoPipeline: the denoising path only runs on an MI355X (HIP kernels); "
+                               "call pipe.to('cuda') — there is no CPU fallback")
+
     @torch.no_grad()
     def _run(self, ref_image, pose_images, ref_pose_image, width, height, video_length, num_inference_steps,
              guidance_scale, num_images_per_prompt, eta, generator, output_type, return_dict, callback, callback_steps,
              windows_fn, latents=None, dp_group=None, decode_chunk=16, return_latents=False):
         device = self._execution_device
-        if device.type != "cuda":
-            raise RuntimeError("Pose2VideoPipeline: the denoising path only runs on an MI355X (HIP kernels); "
-                               "call pipe.to('cuda') — there is no CPU fallback")
+        self._require_gpu(device)
         if num_images_per_prompt != 1:
             raise NotImplementedError("num_images_per_prompt != 1")
         if eta != 0.0:

@@ -230,7 +230,7 @@ def main():
             }
             os.makedirs(os.path.join(REPO, "gpurun_out"), exist_ok=True)
             with open(os.path.join(REPO, "gpurun_out", "bench_kernels_table.json"), "w") as f:
-                json.dump({"clip_kernel_ms": total_ms, "kernels": table}, f, indent=1)
+                json.dump({"clip_kernel_ms": total_ms, "kernels": table, "by_shape": prof.by_shape}, f, indent=1)
         if n_gpus == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

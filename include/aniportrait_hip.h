@@ -175,6 +175,10 @@ enum {
 };
 int anip_profile_enable(int on);
 int anip_profile_collect(int max_ids, int64_t* launches, double* total_ms);
+/* same, and additionally the individual records in launch order: rec_kid[i] / rec_ms[i] for the first
+ * max_records brackets, *n_records = number of brackets seen (per-shape tables of bench.py) */
+int anip_profile_collect_records(int max_ids, int64_t* launches, double* total_ms, int64_t max_records,
+                                 int* rec_kid, float* rec_ms, int64_t* n_records);
 const char* anip_profile_kernel_name(int kid);
 
 #ifdef __cplusplus

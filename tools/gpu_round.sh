@@ -7,7 +7,7 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 echo "== pytest -m gpu"; 
-timeout 900 python -m pytest tests -m gpu -x -q -s > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
+timeout 900 python -m pytest tests -m gpu -q -s > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log
 tail -n 3 $OUT/pytest_gpu.log
 echo "== bench"
 timeout 600 python bench.py > $OUT/bench.log 2>&1; echo "bench rc=$?" | tee -a $OUT/bench.log
