@@ -32,13 +32,42 @@ struct RefAttnArgs {
   int vt_vec_ok, vtref_vec_ok;
 };
 
-template <int D>
+// raw v_exp_f32 (no denormal fix-up sequence around it: inputs here are <= ~THR and results below 2^-126
+// may flush to zero) and packed round-toward-zero fp32 -> fp16 conversion of the probabilities.  The
+// truncation bias is common to the numerator (P V) and — with the ones-row trick below — the denominator.
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+union H2U {
+  fp16x2_t h;
+  unsigned int u;
+};
+__device__ __forceinline__ unsigned int pk_f16(float a, float b) {
+  H2U t;
+  t.h = __builtin_amdgcn_cvt_pkrtz(a, b);
+  return t.u;
+}
+
+// Online softmax is the VALU-bound part of this kernel at d = 40 (rocprofv3: SQ_ACTIVE_INST_VALU 88 % of the
+// kernel's cycles vs 23 % MFMA busy before this restructuring), so the per-score VALU work is cut to
+// max3 / fma / v_exp / cvt_pk:
+//  * the running max is only raised (and O rescaled) when some query's tile max exceeds it by more than
+//    2^RESCALE_LOG2 (lazy rescale): probabilities stay <= 2^RESCALE_LOG2, exact in fp16/fp32 either way;
+//  * when D is not a multiple of 32, row D of the zero-padded V^T tile is set to ones, so the softmax
+//    denominator falls out of the P V MFMA (row D of O^T) instead of 32 VALU adds per tile.
+constexpr float RESCALE_LOG2 = 8.0f;
+
+// FAST: T % 64 == 0 and 16-B aligned V^T rows (every C2 shape): no key masking, branch-free 16-B loads with
+// 32-bit per-thread offsets from a wave-uniform base.
+template <int D, bool FAST>
 __global__ __launch_bounds__(NT, (D > 96 ? 1 : 2)) void ref_attn_kernel(const RefAttnArgs a) {
   constexpr int DQ = (D + 15) / 16;        // 16-wide contraction chunks of Q K^T
   constexpr int DO = (D + 31) / 32;        // 32-row output tiles of O^T
   constexpr int KROW = DQ * 16 + 8;        // fp16 per K LDS row; (2*DQ+1) 16-B slots: odd
   constexpr int DC = D / 8;                // 16-B chunks per head row
   constexpr int NCH = (KV * DC + NT - 1) / NT;  // staged chunks per thread (K and V^T each)
+  constexpr bool ONES = (D % 32) != 0;     // spare padded V^T row available for the denominator
+  constexpr int LT = D / 32, LR = D % 32;  // O^T tile / row of the ones-row
+  constexpr int L_HI = (LR >> 2) & 1, L_REG = 4 * (LR >> 3) + (LR & 3);
   static_assert(D % 8 == 0, "head dim must be a multiple of 8");
   __shared__ __attribute__((aligned(16))) f16 sK[2][KV * KROW];
   __shared__ __attribute__((aligned(16))) f16 sV[2][DO * 32 * VROW];
@@ -54,6 +83,10 @@ __global__ __launch_bounds__(NT, (D > 96 ? 1 : 2)) void ref_attn_kernel(const Re
   // zero the padding that is never overwritten: K columns [D, DQ*16) and V^T rows [D, DO*32)
   for (int i = tid; i < 2 * KV * KROW; i += NT) (&sK[0][0])[i] = (f16)0.f;
   for (int i = tid; i < 2 * DO * 32 * VROW; i += NT) (&sV[0][0])[i] = (f16)0.f;
+  if (ONES) {
+    __syncthreads();
+    for (int i = tid; i < 2 * VROW; i += NT) sV[i / VROW][D * VROW + (i % VROW)] = (f16)1.f;
+  }
 
   // Q fragments (B operand of S^T = K Q^T): lane (q = ql, hi) holds Q[q][16 kk + 8 hi .. +7]
   f16x8 qf[DQ];
@@ -72,39 +105,66 @@ __global__ __launch_bounds__(NT, (D > 96 ? 1 : 2)) void ref_attn_kernel(const Re
   const int nts = (T + KV - 1) / KV;
   const int ntiles = nts * (ref >= 0 ? 2 : 1);
 
+  // per-thread staging bookkeeping, hoisted out of the tile loop
+  bool ch_ok[NCH];
+  int k_key[NCH], k_dc8[NCH], v_dr[NCH], v_k8[NCH];
+  int k_lds[NCH], v_lds_lo[NCH], v_lds_hi[NCH];
+  uint32_t koff_s[NCH], koff_r[NCH], voff_s[NCH], voff_r[NCH];  // FAST: element offsets inside a tile
+#pragma unroll
+  for (int i = 0; i < NCH; ++i) {
+    const int c = tid + i * NT;
+    ch_ok[i] = c < KV * DC;
+    const int cc = ch_ok[i] ? c : 0;       // idle slots re-read chunk 0 (valid memory) and skip the LDS store
+    const int key = cc / DC, dc = cc - key * DC;
+    k_key[i] = key;
+    k_dc8[i] = dc * 8;
+    k_lds[i] = key * KROW + dc * 8;
+    const int dr = cc >> 3, kc = cc & 7;
+    v_dr[i] = dr;
+    v_k8[i] = kc * 8;
+    // 16-key group permutation: [k0-3 | k8-11 | k4-7 | k12-15]
+    const int gb = (kc >> 1) * 16;
+    v_lds_lo[i] = dr * VROW + gb + ((kc & 1) ? 4 : 0);
+    v_lds_hi[i] = dr * VROW + gb + ((kc & 1) ? 12 : 8);
+    koff_s[i] = (uint32_t)(key * (int)a.ldk + dc * 8);
+    koff_r[i] = (uint32_t)(key * (int)a.ldkr + dc * 8);
+    voff_s[i] = (uint32_t)(dr * (int)a.ldvt + kc * 8);
+    voff_r[i] = (uint32_t)(dr * (int)a.ldvtr + kc * 8);
+  }
+
   u32x4 rk[NCH], rv[NCH];
   auto load_tile = [&](int t) {
     const bool second = t >= nts;
     const int tt = second ? t - nts : t;
-    const f16* kb = second ? a.kref : a.k;
     const int64_t ldk = second ? a.ldkr : a.ldk;
-    const f16* vb = second ? a.vtref : a.vt;
     const int64_t ldv = second ? a.ldvtr : a.ldvt;
-    const int64_t tok0 = (int64_t)(second ? ref : n) * T;
+    const int64_t tok0 = (int64_t)(second ? ref : n) * T + (int64_t)tt * KV;
+    const f16* kb = (second ? a.kref : a.k) + tok0 * ldk + h * D;
+    const f16* vb = (second ? a.vtref : a.vt) + (int64_t)h * D * ldv + tok0;
+    if (FAST) {
+#pragma unroll
+      for (int i = 0; i < NCH; ++i) {
+        rk[i] = *(const u32x4*)(kb + (second ? koff_r[i] : koff_s[i]));
+        rv[i] = *(const u32x4*)(vb + (second ? voff_r[i] : voff_s[i]));
+      }
+      return;
+    }
     const bool vvec = second ? a.vtref_vec_ok : a.vt_vec_ok;
+    const int left = T - tt * KV;          // valid keys in this tile (>= KV except in a segment's last tile)
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = tid + i * NT;
       rk[i] = u32x4{0u, 0u, 0u, 0u};
       rv[i] = u32x4{0u, 0u, 0u, 0u};
-      if (c < KV * DC) {
-        {  // K chunk: key = c / DC, d-chunk = c % DC
-          const int key = c / DC, dc = c - key * DC;
-          const int kg = tt * KV + key;
-          if (kg < T) rk[i] = *(const u32x4*)(kb + (tok0 + kg) * ldk + h * D + dc * 8);
-        }
-        {  // V^T chunk: d row = c / 8, keys 8*(c%8) .. +7
-          const int dr = c >> 3, kc = c & 7;
-          const int kg = tt * KV + kc * 8;
-          const f16* vp = vb + (int64_t)(h * D + dr) * ldv + tok0 + kg;
-          if (vvec && kg + 8 <= T) {
-            rv[i] = *(const u32x4*)vp;
-          } else {
-            U4H8 t8;
+      if (ch_ok[i]) {
+        if (k_key[i] < left) rk[i] = *(const u32x4*)(kb + (int64_t)k_key[i] * ldk + k_dc8[i]);
+        const f16* vp = vb + (int64_t)v_dr[i] * ldv + v_k8[i];
+        if (vvec && v_k8[i] + 8 <= left) {
+          rv[i] = *(const u32x4*)vp;
+        } else {
+          U4H8 t8;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) t8.e[e] = (kg + e < T) ? vp[e] : (f16)0.f;
-            rv[i] = t8.u;
-          }
+          for (int e = 0; e < 8; ++e) t8.e[e] = (v_k8[i] + e < left) ? vp[e] : (f16)0.f;
+          rv[i] = t8.u;
         }
       }
     }
@@ -112,16 +172,10 @@ __global__ __launch_bounds__(NT, (D > 96 ? 1 : 2)) void ref_attn_kernel(const Re
   auto store_tile = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-      const int c = tid + i * NT;
-      if (c < KV * DC) {
-        const int key = c / DC, dc = c - key * DC;
-        *(u32x4*)(&sK[buf][key * KROW + dc * 8]) = rk[i];
-        // 16-key group permutation: [k0-3 | k8-11 | k4-7 | k12-15]
-        const int dr = c >> 3, kc = c & 7;
-        const int gb = (kc >> 1) * 16;
-        const int plo = gb + ((kc & 1) ? 4 : 0), phi = gb + ((kc & 1) ? 12 : 8);
-        *(u32x2*)(&sV[buf][dr * VROW + plo]) = u32x2{rv[i].x, rv[i].y};
-        *(u32x2*)(&sV[buf][dr * VROW + phi]) = u32x2{rv[i].z, rv[i].w};
+      if (ch_ok[i]) {
+        *(u32x4*)(&sK[buf][k_lds[i]]) = rk[i];
+        *(u32x2*)(&sV[buf][v_lds_lo[i]]) = u32x2{rv[i].x, rv[i].y};
+        *(u32x2*)(&sV[buf][v_lds_hi[i]]) = u32x2{rv[i].z, rv[i].w};
       }
     }
   };
@@ -131,10 +185,13 @@ __global__ __launch_bounds__(NT, (D > 96 ? 1 : 2)) void ref_attn_kernel(const Re
   for (int dt = 0; dt < DO; ++dt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
+  float m_run = -INFINITY;   // reference max of the exponent (raised lazily), raw-score units
+  float l_run = 0.f;         // denominator when there is no spare V^T row (!ONES)
   const float c2 = a.scale_log2e;
+  const int ka_off = ql * KROW + hi * 8;
+  const int va_off = ql * VROW + hi * 8;
 
-  __syncthreads();  // padding zeros visible before the first tile is written
+  __syncthreads();  // padding zeros / ones visible before the first tile is written
   load_tile(0);
   store_tile(0);
   __syncthreads();
@@ -147,16 +204,17 @@ __global__ __launch_bounds__(NT, (D > 96 ? 1 : 2)) void ref_attn_kernel(const Re
     f32x16 s0, s1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
+    const f16* kbuf = &sK[buf][ka_off];
 #pragma unroll
     for (int kk = 0; kk < DQ; ++kk) {
-      const f16x8 a0 = *(const f16x8*)(&sK[buf][ql * KROW + kk * 16 + hi * 8]);
-      const f16x8 a1 = *(const f16x8*)(&sK[buf][(32 + ql) * KROW + kk * 16 + hi * 8]);
+      const f16x8 a0 = *(const f16x8*)(kbuf + kk * 16);
+      const f16x8 a1 = *(const f16x8*)(kbuf + 32 * KROW + kk * 16);
       s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, qf[kk], s0, 0, 0, 0);
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, qf[kk], s1, 0, 0, 0);
     }
     // mask keys beyond the segment length (last tile of a segment only)
     const int tt = t >= nts ? t - nts : t;
-    if (tt * KV + KV > T) {
+    if (!FAST && tt * KV + KV > T) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = tt * KV + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -165,44 +223,47 @@ __global__ __launch_bounds__(NT, (D > 96 ? 1 : 2)) void ref_attn_kernel(const Re
       }
     }
     // ---- online softmax (one query per lane; partner lane^32 holds the other 32 keys) ------------
-    float mx = s0[0];
+    float mx = fmaxf(fmaxf(s0[0], s0[1]), s0[2]);
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s0[r]);
+    for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s0[r]), s0[r + 1]);
+    mx = fmaxf(fmaxf(mx, s0[15]), s1[0]);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s1[r]);
+    for (int r = 1; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s1[r]), s1[r + 1]);
+    mx = fmaxf(mx, s1[15]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f((m_run - m_new) * c2);
-    const float mb = m_new * c2;
-    float psum = 0.f;
+    if (__any((mx - m_run) * c2 > RESCALE_LOG2)) {   // wave-uniform; always taken on the first tile
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = fast_exp2((m_run - m_new) * c2);
+      m_run = m_new;
+      l_run *= alpha;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s0[r] = exp2f(s0[r] * c2 - mb);
-      s1[r] = exp2f(s1[r] * c2 - mb);
-      psum += s0[r] + s1[r];
+      for (int dt = 0; dt < DO; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
     }
-    l_run = l_run * alpha + psum;
-    m_run = m_new;
-#pragma unroll
-    for (int dt = 0; dt < DO; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    const float mb = m_run * c2;
     // P^T fragments (B operand): k-slot (hi, j) of 16-key group g <-> accumulator reg 8*(g&1)+j of tile g>>1
-    f16x8 pb[4];
+    U4H8 pb[4];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      pb[0][j] = (f16)s0[j];
-      pb[1][j] = (f16)s0[8 + j];
-      pb[2][j] = (f16)s1[j];
-      pb[3][j] = (f16)s1[8 + j];
+    for (int j = 0; j < 8; j += 2) {
+      const float p00 = fast_exp2(fmaf(s0[j], c2, -mb)), p01 = fast_exp2(fmaf(s0[j + 1], c2, -mb));
+      const float p10 = fast_exp2(fmaf(s0[8 + j], c2, -mb)), p11 = fast_exp2(fmaf(s0[9 + j], c2, -mb));
+      const float p20 = fast_exp2(fmaf(s1[j], c2, -mb)), p21 = fast_exp2(fmaf(s1[j + 1], c2, -mb));
+      const float p30 = fast_exp2(fmaf(s1[8 + j], c2, -mb)), p31 = fast_exp2(fmaf(s1[9 + j], c2, -mb));
+      if (!ONES) l_run += ((p00 + p01) + (p10 + p11)) + ((p20 + p21) + (p30 + p31));
+      pb[0].u[j >> 1] = pk_f16(p00, p01);
+      pb[1].u[j >> 1] = pk_f16(p10, p11);
+      pb[2].u[j >> 1] = pk_f16(p20, p21);
+      pb[3].u[j >> 1] = pk_f16(p30, p31);
     }
     // ---- O^T += V^T P^T ------------------------------------------------------------------------
+    const f16* vbuf = &sV[buf][va_off];
 #pragma unroll
     for (int dt = 0; dt < DO; ++dt) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f16x8 av = *(const f16x8*)(&sV[buf][(dt * 32 + ql) * VROW + g * 16 + hi * 8]);
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, pb[g], o[dt], 0, 0, 0);
+        const f16x8 av = *(const f16x8*)(vbuf + dt * 32 * VROW + g * 16);
+        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, pb[g].h, o[dt], 0, 0, 0);
       }
     }
     if (more) store_tile(buf ^ 1);
@@ -210,7 +271,14 @@ __global__ __launch_bounds__(NT, (D > 96 ? 1 : 2)) void ref_attn_kernel(const Re
   }
 
   // ---- epilogue -------------------------------------------------------------------------------------
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  float l_tot;
+  if (ONES) {
+    const float lv = o[LT][L_REG];                 // row D of O^T: held by the half-wave with hi == L_HI
+    const float lp = __shfl_xor(lv, 32, 64);
+    l_tot = (hi == L_HI) ? lv : lp;
+  } else {
+    l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  }
   const float inv = 1.0f / l_tot;
   if (qvalid) {
     f16* op = a.out + ((int64_t)n * T + q) * a.ldo + h * D;
@@ -233,7 +301,11 @@ template <int D>
 int launch_ref_attn(const RefAttnArgs& a, int Nf, hipStream_t stream) {
   dim3 grid((unsigned)((a.T + 127) / 128), (unsigned)a.heads, (unsigned)Nf);
   AnipProfScope prof_(ANIP_K_REF_ATTN, (void*)stream);
-  hipLaunchKernelGGL(ref_attn_kernel<D>, grid, dim3(NT), 0, stream, a);
+  const bool fits32 = (int64_t)KV * a.ldk < (1ll << 31) && (int64_t)KV * a.ldkr < (1ll << 31) &&
+                      (int64_t)(D + 32) * a.ldvt < (1ll << 31) && (int64_t)(D + 32) * a.ldvtr < (1ll << 31);
+  const bool fast = (a.T % KV) == 0 && a.vt_vec_ok && (a.ref_index == nullptr || a.vtref_vec_ok) && fits32;
+  if (fast) hipLaunchKernelGGL((ref_attn_kernel<D, true>), grid, dim3(NT), 0, stream, a);
+  else hipLaunchKernelGGL((ref_attn_kernel<D, false>), grid, dim3(NT), 0, stream, a);
   return 0;
 }
 

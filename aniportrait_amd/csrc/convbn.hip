@@ -15,9 +15,10 @@ constexpr int NT = 256;
 // the weights sit in LDS and the 8 weights of one (tap, ci) are ONE 16-B broadcast read.
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void conv_direct_kernel(const f16* __restrict__ x, const f16* __restrict__ wp,
-                                                        const float* __restrict__ bias, f16* __restrict__ y, int N,
-                                                        int H, int W, int Cin, int Cout, int Cout8, int ks, int stride,
-                                                        int pad, int Ho, int Wo, int pix_per_block, int relu) {
+                                                        const float* __restrict__ bias, const f16* __restrict__ res,
+                                                        f16* __restrict__ y, int N, int H, int W, int Cin, int Cout,
+                                                        int Cout8, int ks, int stride, int pad, int Ho, int Wo,
+                                                        int pix_per_block, int relu) {
   extern __shared__ __attribute__((aligned(16))) f16 sw[];
   const int tid = threadIdx.x;
   const int nw8 = ks * ks * Cin * (Cout8 >> 3);
@@ -27,6 +28,7 @@ __global__ __launch_bounds__(NT) void conv_direct_kernel(const f16* __restrict__
   const int64_t npix = (int64_t)N * Ho * Wo;
   const int64_t pix0 = (int64_t)blockIdx.x * pix_per_block;
   const bool vec_in = (Cin & 7) == 0;
+  const bool vec4_in = Cin == 4;
   for (int o = tid; o < pix_per_block * cg_n; o += NT) {
     const int pl = o / cg_n, cg = o - pl * cg_n;
     const int64_t pix = pix0 + pl;
@@ -59,6 +61,17 @@ __global__ __launch_bounds__(NT) void conv_direct_kernel(const f16* __restrict__
               for (int e = 0; e < 8; ++e) acc[e] += xf * (float)wv.e[e];
             }
           }
+        } else if (vec4_in) {
+          union { u32x2 u; f16 e[4]; } xv;
+          xv.u = *(const u32x2*)xp;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            U4H8 wv;
+            wv.u = *(const u32x4*)(wt + j * Cout8);
+            const float xf = (float)xv.e[j];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += xf * (float)wv.e[e];
+          }
         } else {
           for (int ci = 0; ci < Cin; ++ci) {
             U4H8 wv;
@@ -70,11 +83,24 @@ __global__ __launch_bounds__(NT) void conv_direct_kernel(const f16* __restrict__
         }
       }
     }
+    f16* yp = y + pix * Cout + co0;
+    if (res != nullptr) {
+      const f16* rp = res + pix * Cout + co0;
+      if ((Cout & 7) == 0) {
+        U4H8 rv;
+        rv.u = *(const u32x4*)rp;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += (float)rv.e[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (co0 + e < Cout) acc[e] += (float)rp[e];
+      }
+    }
     if (relu) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] = fmaxf(acc[e], 0.f);
     }
-    f16* yp = y + pix * Cout + co0;
     if ((Cout & 7) == 0) {
       U4H8 ov;
 #pragma unroll
@@ -232,13 +258,14 @@ inline int bn_blocks(int64_t M, int C) {
 
 }  // namespace
 
-extern "C" int anip_conv_direct(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Cin,
-                                int Cout, int ksize, int stride, int pad, int relu, void* stream) {
+extern "C" int anip_conv_direct(const void* x, const void* wp, const float* bias, const void* residual, void* y, int N,
+                                int H, int W, int Cin, int Cout, int ksize, int stride, int pad, int relu, void* stream) {
   ANIP_REQUIRE(x && wp && y, "anip_conv_direct: null pointer");
   ANIP_REQUIRE(ksize >= 1 && ksize <= 5 && (stride == 1 || stride == 2) && pad >= 0 && pad < ksize,
                "anip_conv_direct: ksize=%d stride=%d pad=%d unsupported", ksize, stride, pad);
   ANIP_REQUIRE(N > 0 && H > 0 && W > 0 && Cin >= 1 && Cout >= 1, "anip_conv_direct: bad sizes");
-  ANIP_REQUIRE((((uintptr_t)x | (uintptr_t)wp | (uintptr_t)y) & 15) == 0, "anip_conv_direct: pointers must be 16-B aligned");
+  ANIP_REQUIRE((((uintptr_t)x | (uintptr_t)wp | (uintptr_t)y | (uintptr_t)residual) & 15) == 0,
+               "anip_conv_direct: pointers must be 16-B aligned");
   const int Cout8 = (Cout + 7) & ~7;
   const size_t lds = (size_t)ksize * ksize * Cin * Cout8 * sizeof(f16);
   ANIP_REQUIRE(lds <= 65536, "anip_conv_direct: weights (%zu B) do not fit in 64 KB of LDS; use anip_gemm (conv)", lds);
@@ -253,7 +280,8 @@ extern "C" int anip_conv_direct(const void* x, const void* wp, const float* bias
   {
     AnipProfScope prof_(ANIP_K_CONV_SMALL, (void*)stream);
     hipLaunchKernelGGL(conv_direct_kernel, dim3((unsigned)blocks), dim3(NT), lds, (hipStream_t)stream, (const f16*)x,
-                       (const f16*)wp, bias, (f16*)y, N, H, W, Cin, Cout, Cout8, ksize, stride, pad, Ho, Wo, ppb, relu);
+                       (const f16*)wp, bias, (const f16*)residual, (f16*)y, N, H, W, Cin, Cout, Cout8, ksize, stride, pad, Ho,
+                       Wo, ppb, relu);
   }
   ANIP_LAUNCH_CHECK("anip_conv_direct");
   return 0;

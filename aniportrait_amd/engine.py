@@ -379,8 +379,8 @@ def unet_forward(net, cfg, x, b, f, t, ehs, attn2_cache, refs, with_motion, ref_
             return x
         return ops.add(x, pose_nhwc[i])
 
-    x = ops.conv_small(x, net.conv_small("conv_in.weight"), net.f32("conv_in.bias"), 3,
-                       residual=None if pose_nhwc is None else pose_nhwc[0])
+    x = ops.conv_direct(x, net.conv_direct("conv_in.weight"), net.f32("conv_in.bias"), boc[0], 3, 1, 1,
+                        residual=None if pose_nhwc is None else pose_nhwc[0])
     skips = [x]
     for i in range(nblk):
         for j in range(lpb):
@@ -446,8 +446,10 @@ def vae_decode(net, cfg, z):
     """AutoencoderKL.decode(z).sample, batched over frames (src/pipelines/pipeline_pose2vid_long.py:119-120
     decodes frame by frame; frames are independent).  z (N, h, w, 4) fp16 -> (N, 8h, 8w, 3) fp16."""
     nb = len(cfg["block_out_channels"])
-    x = ops.conv_small(z, net.conv_small("post_quant_conv.weight"), net.f32("post_quant_conv.bias"), 1)
-    x = ops.conv_small(x, net.conv_small("decoder.conv_in.weight"), net.f32("decoder.conv_in.bias"), 3)
+    x = ops.conv_direct(z, net.conv_direct("post_quant_conv.weight"), net.f32("post_quant_conv.bias"),
+                        cfg["latent_channels"], 1, 1, 0)
+    x = ops.conv_direct(x, net.conv_direct("decoder.conv_in.weight"), net.f32("decoder.conv_in.bias"),
+                        cfg["block_out_channels"][-1], 3, 1, 1)
     x = _vae_mid(net, "decoder.mid_block", x)
     for i in range(nb):
         for j in range(cfg["layers_per_block"] + 1):
@@ -465,7 +467,8 @@ def vae_encode_mean(net, cfg, x):
     """AutoencoderKL.encode(x).latent_dist.mean (src/pipelines/pipeline_pose2vid_long.py:430).
     x (N, H, W, 3) fp16 -> (N, H/8, W/8, latent_channels) fp16."""
     nb = len(cfg["block_out_channels"])
-    x = ops.conv_small(x, net.conv_small("encoder.conv_in.weight"), net.f32("encoder.conv_in.bias"), 3)
+    x = ops.conv_direct(x, net.conv_direct("encoder.conv_in.weight"), net.f32("encoder.conv_in.bias"),
+                        cfg["block_out_channels"][0], 3, 1, 1)
     for i in range(nb):
         for j in range(cfg["layers_per_block"]):
             x = resnet(net, f"encoder.down_blocks.{i}.resnets.{j}", x, None, None, 0, 1e-6)

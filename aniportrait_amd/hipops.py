@@ -306,8 +306,8 @@ def pack_conv_direct(w):
     return wp.contiguous()
 
 
-def conv_direct(x, wp, bias, Cout, ksize, stride=1, pad=1, relu=False):
-    """x (N, H, W, Cin) fp16, wp from pack_conv_direct -> (N, Ho, Wo, Cout) fp16."""
+def conv_direct(x, wp, bias, Cout, ksize, stride=1, pad=1, relu=False, residual=None):
+    """x (N, H, W, Cin) fp16, wp from pack_conv_direct [, residual (N, Ho, Wo, Cout)] -> (N, Ho, Wo, Cout) fp16."""
     lib = L.load()
     _req(x, F16, "x")
     _req(wp, F16, "wp")
@@ -317,7 +317,10 @@ def conv_direct(x, wp, bias, Cout, ksize, stride=1, pad=1, relu=False):
     Wo = (Wd + 2 * pad - ksize) // stride + 1
     y = torch.empty((N, Ho, Wo, Cout), dtype=F16, device=x.device)
     _work(K_CONV_SMALL, x.numel() * 2 + y.numel() * 2, f"direct N{N} {H}x{Wd} Cin{Cin} Cout{Cout} k{ksize} s{stride}")
-    L.check(lib.anip_conv_direct(_p(x), _p(wp), _p(bias), _p(y), N, H, Wd, Cin, Cout, ksize, stride, pad,
+    if residual is not None:
+        _req(residual, F16, "residual")
+        assert residual.numel() == y.numel()
+    L.check(lib.anip_conv_direct(_p(x), _p(wp), _p(bias), _p(residual), _p(y), N, H, Wd, Cin, Cout, ksize, stride, pad,
                                  int(bool(relu)), _stream()), "anip_conv_direct")
     return y
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ANIP_ABI_VERSION 3
+#define ANIP_ABI_VERSION 4
 
 int anip_version(void);
 const char* anip_last_error(void);
@@ -94,13 +94,15 @@ int anip_conv_small(const void* x, const void* w, const float* bias, const void*
  * replaces the nn.Conv2d / nn.BatchNorm2d / nn.ReLU stacks of src/models/pose_guider.py:19-85 whose channel
  * counts (3, 16, 32) or 4x4-stride-2 windows do not fit the implicit-GEMM kernel.
  * anip_conv_direct: x [N,H,W,Cin] fp16; wp [ksize*ksize*Cin][Cout8] fp16 with Cout8 = Cout rounded up to 8
- * (tap-major, output channel fastest, zero padded); bias fp32 [Cout] or NULL; y [N,Ho,Wo,Cout] fp16,
+ * (tap-major, output channel fastest, zero padded); bias fp32 [Cout] or NULL; residual [N,Ho,Wo,Cout] fp16 or
+ * NULL (added before the optional ReLU: the pose-feature add of src/models/unet_3d.py:485-486 on conv_in, which —
+ * like AutoencoderKL post_quant_conv / decoder.conv_in / encoder.conv_in — also runs here); y [N,Ho,Wo,Cout] fp16,
  * Ho = (H + 2 pad - ksize) / stride + 1.  ksize 1..5, stride 1 or 2; ksize*ksize*Cin*Cout8*2 <= 64 KB.
  * anip_batchnorm: x,y [M][C] fp16 (channels-last rows = N*H*W); running_mean/var NULL -> batch statistics
  * with biased variance (module in training mode: scripts/pose2vid.py:77 never calls .eval()), else the
  * running statistics.  ws: fp32 workspace of anip_batchnorm_ws_floats(M, C) elements. */
-int anip_conv_direct(const void* x, const void* wp, const float* bias, void* y, int N, int H, int W, int Cin,
-                     int Cout, int ksize, int stride, int pad, int relu, void* stream);
+int anip_conv_direct(const void* x, const void* wp, const float* bias, const void* residual, void* y, int N, int H,
+                     int W, int Cin, int Cout, int ksize, int stride, int pad, int relu, void* stream);
 int64_t anip_batchnorm_ws_floats(int64_t M, int C);
 int anip_batchnorm(const void* x, const float* gamma, const float* beta, const float* running_mean,
                    const float* running_var, void* y, int64_t M, int C, float eps, int relu, float* ws,

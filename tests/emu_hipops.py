@@ -107,13 +107,16 @@ def conv_small(x, w, bias, ksize, residual=None):
     return y.to(F16).contiguous()
 
 
-def conv_direct(x, wp, bias, Cout, ksize, stride=1, pad=1, relu=False):
+def conv_direct(x, wp, bias, Cout, ksize, stride=1, pad=1, relu=False, residual=None):
     Cin = x.shape[-1]
     w = wp.float()[:, :Cout].reshape(ksize, ksize, Cin, Cout).permute(3, 2, 0, 1)
     y = F.conv2d(x.float().permute(0, 3, 1, 2), w, None if bias is None else bias.float(), stride=stride, padding=pad)
+    y = y.permute(0, 2, 3, 1)
+    if residual is not None:
+        y = y + residual.float().reshape(y.shape)
     if relu:
         y = F.relu(y)
-    return y.permute(0, 2, 3, 1).to(F16).contiguous()
+    return y.to(F16).contiguous()
 
 
 def batchnorm(x, gamma, beta, running_mean=None, running_var=None, eps=1e-5, relu=True):

@@ -278,6 +278,57 @@ def test_ref_attention_growing_max():
     close(out, ref, "ref_attention growing max", rtol=4e-3, arms=4e-3)
 
 
+@pytest.mark.parametrize("d", [40, 64, 80, 160])
+@pytest.mark.parametrize("T", [512, 500])
+@pytest.mark.parametrize("order", ["up", "down", "spike"])
+def test_ref_attention_lazy_rescale(d, T, order):
+    """The running max is raised lazily (only when a tile max exceeds it by > 2^8): ramps of 60 log2 units over
+    the keys (ascending: many rescales; descending: later tiles underflow to zero) and isolated spikes must
+    match an independent fp64 softmax.  T = 512 takes the branch-free path, T = 500 the masked one."""
+    ops = _ops()
+    heads, Nf = 1, 1
+    g = 60.0 * math.log(2.0) / math.sqrt(d)
+    ramp = torch.arange(T).float() / T
+    if order == "down":
+        ramp = ramp.flip(0)
+    if order == "spike":
+        ramp = torch.zeros(T)
+        ramp[[70, 71, 200, 333, T - 1]] = torch.tensor([0.3, 0.31, 0.6, 0.9, 1.0])
+    q = torch.ones(T, d).half()
+    q[1::2] *= 0.5                                              # half the queries see half the ramp
+    k = (ramp[:, None] * g * torch.ones(T, d)).half()
+    v = rnd(T, d, seed=75)
+    out = ops.ref_attention(q.to(DEV), d, k.to(DEV), d, v.t().contiguous().to(DEV), T, Nf, T, heads, d)
+    p = torch.softmax(q.double() @ k.double().t() * d ** -0.5, dim=-1)
+    close(out, (p @ v.double()).float(), f"ref_attention lazy rescale d={d} T={T} {order}", rtol=6e-3, arms=6e-3)
+
+
+@pytest.mark.parametrize("d,T", [(40, 1024), (80, 1024), (160, 256)])
+def test_ref_attention_peaky_with_reference(d, T):
+    """large-|score| random inputs (peaky softmax) with a reference segment and a CFG-unconditional frame"""
+    ops = _ops()
+    heads, Nf = 8, 2
+    Cc = heads * d
+    qk = rnd(Nf * T, 2 * Cc, seed=76, scale=2.0).to(DEV)
+    v = rnd(Nf * T, Cc, seed=77).to(DEV)
+    kref = rnd(T, Cc, seed=78, scale=2.0).to(DEV)
+    vref = rnd(T, Cc, seed=79).to(DEV)
+    ref_index = torch.tensor([-1, 0], dtype=torch.int32, device=DEV)
+    out = ops.ref_attention(qk, 2 * Cc, qk[:, Cc:], 2 * Cc, v.t().contiguous(), Nf * T, Nf, T, heads, d, kref=kref,
+                            ldkr=Cc, vtref=vref.t().contiguous(), ldvtr=T, ref_index=ref_index)
+    refs = []
+    for n in range(Nf):
+        q_ = qk[n * T:(n + 1) * T, :Cc].double().reshape(T, heads, d).transpose(0, 1)
+        k_ = qk[n * T:(n + 1) * T, Cc:].double().reshape(T, heads, d).transpose(0, 1)
+        v_ = v[n * T:(n + 1) * T].double().reshape(T, heads, d).transpose(0, 1)
+        if int(ref_index[n]) >= 0:
+            k_ = torch.cat([k_, kref.double().reshape(T, heads, d).transpose(0, 1)], 1)
+            v_ = torch.cat([v_, vref.double().reshape(T, heads, d).transpose(0, 1)], 1)
+        p = torch.softmax(q_ @ k_.transpose(-1, -2) * d ** -0.5, dim=-1)
+        refs.append((p @ v_).transpose(0, 1).reshape(T, Cc).float())
+    close(out, torch.cat(refs, 0), f"ref_attention peaky d={d} T={T}", rtol=6e-3, arms=6e-3)
+
+
 @pytest.mark.parametrize("B,Fr,T,heads,d", [(2, 16, 10, 8, 40), (1, 4, 7, 8, 8), (1, 24, 3, 8, 160), (2, 5, 6, 2, 16),
                                             (1, 32, 2, 8, 80)])
 def test_temporal_attention(B, Fr, T, heads, d):
@@ -466,7 +517,8 @@ def test_layernorm_shapes(M, C):
 # ------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("N,H,W,Cin,Cout,ks,stride,pad", [
     (2, 32, 32, 3, 3, 3, 1, 1), (2, 32, 32, 3, 16, 4, 2, 1), (1, 17, 23, 16, 16, 3, 1, 1), (2, 16, 16, 16, 32, 4, 2, 1),
-    (1, 20, 12, 32, 64, 4, 2, 1), (3, 9, 9, 8, 24, 3, 2, 1), (1, 8, 8, 5, 7, 1, 1, 0), (4, 128, 128, 3, 16, 4, 2, 1)])
+    (1, 20, 12, 32, 64, 4, 2, 1), (3, 9, 9, 8, 24, 3, 2, 1), (1, 8, 8, 5, 7, 1, 1, 0), (4, 128, 128, 3, 16, 4, 2, 1),
+    (2, 32, 32, 4, 320, 3, 1, 1), (2, 16, 16, 4, 4, 1, 1, 0), (1, 16, 16, 4, 512, 3, 1, 1), (1, 24, 24, 3, 128, 3, 1, 1)])
 def test_conv_direct(N, H, W, Cin, Cout, ks, stride, pad):
     ops = _ops()
     x = rnd(N, H, W, Cin, seed=1).to(DEV)
@@ -478,6 +530,11 @@ def test_conv_direct(N, H, W, Cin, Cout, ks, stride, pad):
         if relu:
             ref = F.relu(ref)
         close(y, ref.permute(0, 2, 3, 1), f"conv_direct {Cin}->{Cout} k{ks} s{stride} relu={relu}")
+    res = rnd(*y.shape, seed=4)
+    y = ops.conv_direct(x, ops.pack_conv_direct(w.to(DEV)), b.to(DEV), Cout, ks, stride, pad, relu=True, residual=res.to(DEV))
+    ref = F.relu(F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.float(), b, stride=stride, padding=pad).permute(0, 2, 3, 1)
+                 + res.float())
+    close(y, ref, f"conv_direct {Cin}->{Cout} k{ks} s{stride} +residual")
 
 
 @pytest.mark.parametrize("M,C", [(4 * 64 * 64, 3), (1000, 16), (33, 64), (70000, 128), (4096, 320), (300, 1280),

@@ -85,6 +85,12 @@ def main():
     quick = "--quick" in sys.argv
     print(json.dumps(dict(device=ops.device_info())), flush=True)
     NF = 32
+    if "--attn" in sys.argv:
+        bench_attn(NF, 4096, 8, 40, "64^2 d40")
+        bench_attn(NF, 1024, 8, 80, "32^2 d80")
+        bench_attn(NF, 256, 8, 160, "16^2 d160")
+        bench_attn(NF, 64, 8, 160, "8^2 d160")
+        return
     # linear layers of the 64^2 / 32^2 / 16^2 levels
     bench_gemm(NF * 4096, 640, 320, "qk-proj 64^2")
     bench_gemm(NF * 4096, 320, 320, "out-proj 64^2")
