@@ -67,6 +67,7 @@ SIGNATURES = {
     "anip_ncfhw_to_nhwc": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int64, c_void_p]),
     "anip_nhwc_to_ncfhw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_float, c_float, c_int,
                                    c_void_p]),
+    "anip_u8_to_f16": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p]),
     "anip_profile_enable": (c_int, [c_int]),
     "anip_profile_collect": (c_int, [c_int, C.POINTER(c_int64), C.POINTER(C.c_double)]),
     "anip_profile_collect_records": (c_int, [c_int, C.POINTER(c_int64), C.POINTER(C.c_double), c_int64,

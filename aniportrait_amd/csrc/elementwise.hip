@@ -195,6 +195,26 @@ __global__ __launch_bounds__(NT) void nhwc_to_ncfhw_kernel(const f16* __restrict
   }
 }
 
+// dst[i] = (f16)(scale * src[i] + shift): uint8 image bytes -> fp16 activations (pose renderings, already
+// channels-last: (L,H,W,3) uint8 IS the NHWC frame batch)
+__global__ __launch_bounds__(NT) void u8_to_f16_kernel(const uint8_t* __restrict__ src, f16* __restrict__ dst, int64_t n,
+                                                      float scale, float shift) {
+  const int64_t stride = (int64_t)gridDim.x * NT;
+  const int64_t nv = n >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < nv; i += stride) {
+    const u32x2 raw = ((const u32x2*)src)[i];
+    U4H8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const unsigned int b = ((e < 4 ? raw.x : raw.y) >> (8 * (e & 3))) & 0xFFu;
+      o.e[e] = (f16)(scale * (float)b + shift);
+    }
+    ((u32x4*)dst)[i] = o.u;
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = (nv << 3) + threadIdx.x; i < n; i += NT) dst[i] = (f16)(scale * (float)src[i] + shift);
+}
+
 inline unsigned grid_for(int64_t work) {
   int64_t b = (work + NT - 1) / NT;
   if (b < 1) b = 1;
@@ -308,5 +328,17 @@ extern "C" int anip_nhwc_to_ncfhw(const void* src, void* dst, int dst_f32, int B
     hipLaunchKernelGGL(nhwc_to_ncfhw_kernel<f16>, dim3(grid_for(total)), dim3(NT), 0, (hipStream_t)stream,
                        (const f16*)src, (f16*)dst, B, C, F, HW, scale, shift, clamp01);
   ANIP_LAUNCH_CHECK("anip_nhwc_to_ncfhw");
+  return 0;
+}
+
+extern "C" int anip_u8_to_f16(const void* src, void* dst, int64_t n, float scale, float shift, void* stream) {
+  ANIP_REQUIRE(src && dst && n > 0, "anip_u8_to_f16: bad arguments");
+  ANIP_REQUIRE(((uintptr_t)src & 7) == 0 && ((uintptr_t)dst & 15) == 0, "anip_u8_to_f16: src must be 8-B, dst 16-B aligned");
+  {
+    AnipProfScope prof_(ANIP_K_ELEMENTWISE, stream);
+    hipLaunchKernelGGL(u8_to_f16_kernel, dim3(grid_for(n / 8 + 1)), dim3(NT), 0, (hipStream_t)stream, (const uint8_t*)src,
+                       (f16*)dst, n, scale, shift);
+  }
+  ANIP_LAUNCH_CHECK("anip_u8_to_f16");
   return 0;
 }

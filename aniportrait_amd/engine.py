@@ -181,13 +181,15 @@ def feed_forward(net, p, n_in, residual):
 class RefState:
     """Reference-attention state of one spatial transformer block (what `module.bank` plus the hacked
     forward's closure hold in src/models/mutual_self_attention.py:93-265)."""
-    __slots__ = ("mode", "bank", "kref", "vtref", "written")
+    __slots__ = ("mode", "bank", "kref", "vtref", "stale", "written")
 
     def __init__(self):
         self.mode = "plain"   # "plain" | "write" | "read"
         self.bank = None      # (b, T, C) fp16 on device (read mode)
         self.kref = None      # (b*T, C) fp16: to_k(bank)
         self.vtref = None     # (C, b*T) fp16: to_v(bank)^T
+        self.stale = True     # bank replaced since kref / vtref were projected: re-project IN PLACE (the buffers
+                              # keep their addresses, which captured hipGraphs of the forward have baked in)
         self.written = None   # (b, T, C) fp16 produced in write mode
 
 
@@ -206,12 +208,16 @@ def transformer_block(net, p, h, Nf, T, heads, attn2_vec, rows_per_sample, ref=N
     vt = ops.gemm(nh, net.lin(p + ".attn1.to_v.weight"), trans_out=True)  # V^T [C][Nf*T]
     kw = {}
     if mode == "read" and ref.bank is not None:
-        if ref.kref is None:
+        if ref.kref is None or ref.stale:
             bank2 = ref.bank.reshape(-1, C)
             if bank2.dtype != F16 or bank2.device != net.device:
                 bank2 = bank2.to(net.device, F16)
-            ref.kref = ops.gemm(bank2, net.lin(p + ".attn1.to_k.weight"))
-            ref.vtref = ops.gemm(bank2, net.lin(p + ".attn1.to_v.weight"), trans_out=True)
+            reuse = (ref.kref is not None and tuple(ref.kref.shape) == (bank2.shape[0], C) and
+                     ref.kref.device == bank2.device)
+            ref.kref = ops.gemm(bank2, net.lin(p + ".attn1.to_k.weight"), out=ref.kref if reuse else None)
+            ref.vtref = ops.gemm(bank2, net.lin(p + ".attn1.to_v.weight"), trans_out=True,
+                                 out=ref.vtref if reuse else None)
+            ref.stale = False
         assert ref.bank.shape[1] == T, "reference bank token count differs from the denoising latents"
         kw = dict(kref=ref.kref, ldkr=C, vtref=ref.vtref, ldvtr=ref.vtref.shape[1], ref_index=ref_index[0],
                   n_ref_frames=ref_index[1])
@@ -320,17 +326,21 @@ class Attn2Cache:
         key = (ehs.data_ptr(), ehs._version, tuple(ehs.shape), ehs.dtype)
         if key != self.key:
             e = ehs.detach().reshape(ehs.shape[0], -1).to(net.device, F32).contiguous()  # (b, D): sequence length 1
-            vecs = {}
+            vecs, old = {}, self.vecs or {}
             for p in attention_paths(cfg):
                 a = p + ".transformer_blocks.0.attn2"
                 v = ops.linear_small(e, net.lin(a + ".to_v.weight"))
-                vecs[p] = ops.linear_small(v, net.lin(a + ".to_out.0.weight"), net.f32(a + ".to_out.0.bias"))
+                Wo = net.lin(a + ".to_out.0.weight")
+                o = old.get(p)   # rewritten in place: captured hipGraphs keep reading the same buffers
+                if o is not None and (tuple(o.shape) != (e.shape[0], Wo.shape[0]) or o.device != e.device):
+                    o = None
+                vecs[p] = ops.linear_small(v, Wo, net.f32(a + ".to_out.0.bias"), out=o)
             self.key, self.vecs = key, vecs
         return self.vecs
 
 
 def unet_forward(net, cfg, x, b, f, t, ehs, attn2_cache, refs, with_motion, ref_index=None, pose_nhwc=None,
-                 final=True, stop_after_last_bank=False):
+                 final=True, stop_after_last_bank=False, temb_in=None):
     """UNet3DConditionModel.forward (src/models/unet_3d.py:399-580) / the ReferenceNet
     UNet2DConditionModel.forward (src/models/unet_2d_condition.py:872-1308, f = 1, no motion modules).
 
@@ -350,7 +360,10 @@ def unet_forward(net, cfg, x, b, f, t, ehs, attn2_cache, refs, with_motion, ref_
     N, H, W, _ = x.shape
     assert N == b * f
 
-    emb = timestep_sinusoid(t, b, boc[0], net.device, cfg.get("flip_sin_to_cos", True), cfg.get("freq_shift", 0))
+    # temb_in: the sinusoid already on the device (fp32 (b, C0)) — lets a captured hipGraph of this forward be
+    # replayed for every DDIM step by rewriting that one buffer
+    emb = temb_in if temb_in is not None else timestep_sinusoid(t, b, boc[0], net.device,
+                                                               cfg.get("flip_sin_to_cos", True), cfg.get("freq_shift", 0))
     emb = ops.linear_small(emb, net.lin("time_embedding.linear_1.weight"), net.f32("time_embedding.linear_1.bias"))
     emb = ops.linear_small(emb, net.lin("time_embedding.linear_2.weight"), net.f32("time_embedding.linear_2.bias"),
                            silu_in=True)

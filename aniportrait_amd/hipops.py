@@ -377,14 +377,15 @@ def softmax_rows(s):
     return p
 
 
-def linear_small(x, W, bias=None, silu_in=False):
-    """x (M<=16, K) fp32, W (N, K) fp16 -> (M, N) fp32."""
+def linear_small(x, W, bias=None, silu_in=False, out=None):
+    """x (M<=16, K) fp32, W (N, K) fp16 -> (M, N) fp32 (written into `out` when given)."""
     lib = L.load()
     _req(x, F32, "x")
     _req(W, F16, "W")
     M, K = x.shape
     N = W.shape[0]
-    y = torch.empty((M, N), dtype=F32, device=x.device)
+    y = torch.empty((M, N), dtype=F32, device=x.device) if out is None else _req(out, F32, "out")
+    assert tuple(y.shape) == (M, N)
     _work(K_LINEAR_SMALL, N * K * 2, f"M{M} N{N} K{K}")
     L.check(lib.anip_linear_small(_p(x), _p(W), _p(bias), _p(y), M, N, K, int(bool(silu_in)), _stream()),
             "anip_linear_small")
@@ -439,4 +440,17 @@ def nhwc_to_ncfhw(src, B, out_f32=False, scale=1.0, shift=0.0, clamp01=False):
     _work(K_ELEMENTWISE, src.numel() * (2 + dst.element_size()), "nhwc_to_ncfhw")
     L.check(lib.anip_nhwc_to_ncfhw(_p(src), _p(dst), int(out_f32), B, Cc, Fr, H * Wd, float(scale), float(shift),
                                    int(bool(clamp01)), _stream()), "anip_nhwc_to_ncfhw")
+    return dst
+
+
+def u8_to_f16(src, scale=1.0, shift=0.0):
+    """uint8 tensor -> fp16 tensor of the same shape: scale * x + shift."""
+    lib = L.load()
+    if not src.is_cuda:
+        raise L.HipLibraryError("u8_to_f16: expected a GPU tensor")
+    if src.dtype != torch.uint8 or not src.is_contiguous():
+        raise TypeError("u8_to_f16: expected a contiguous uint8 tensor")
+    dst = torch.empty(src.shape, dtype=F16, device=src.device)
+    _work(K_ELEMENTWISE, src.numel() * 3, "u8_to_f16")
+    L.check(lib.anip_u8_to_f16(_p(src), _p(dst), src.numel(), float(scale), float(shift), _stream()), "anip_u8_to_f16")
     return dst

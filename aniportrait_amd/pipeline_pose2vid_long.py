@@ -17,17 +17,95 @@ Extra keyword arguments (all optional, reference callers never pass them):
 """
 import inspect
 import math
+import os
+import time
 
 import numpy as np
 import torch
 
 from . import distributed as D
+from . import engine
 from . import hipops as ops
 from .autoencoder_kl import AutoencoderKL
 from .context import get_context_scheduler
 from .image_processor import VaeImageProcessor, randn_tensor
 from .modeling import BaseOutput
 from .mutual_self_attention import ReferenceAttentionControl
+
+
+class _StageTimer:
+    """ANIP_PIPE_TIMING=1: synchronised wall time per pipeline stage, printed at the end of the call."""
+
+    def __init__(self):
+        self.on = bool(os.environ.get("ANIP_PIPE_TIMING"))
+        self.t0 = self.last = time.perf_counter()
+        self.rows = []
+
+    def mark(self, name):
+        if self.on:
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            self.rows.append((name, (now - self.last) * 1e3))
+            self.last = now
+
+    def report(self):
+        if self.on:
+            tot = (time.perf_counter() - self.t0) * 1e3
+            print("[pipe timing] " + "  ".join(f"{n}={ms:.1f}ms" for n, ms in self.rows) + f"  total={tot:.1f}ms",
+                  flush=True)
+
+
+class _DenoiseRunner:
+    """Static-buffer front of `UNet3DConditionModel.forward_nhwc` for one window shape (CFG batch S, f frames,
+    latent h x w), kept on the pipeline across clips.  All per-call inputs live in persistent device buffers
+    (x, timestep sinusoid, CLIP token, the 5 pose feature maps); the reference-bank projections and the
+    collapsed-attn2 vectors are refreshed IN PLACE by the eager forward of every clip's first DDIM step
+    (engine.transformer_block / engine.Attn2Cache).  That makes the forward — about 640 kernel launches —
+    a hipGraph captured once and replayed for every later (step, window, clip)."""
+
+    def __init__(self, unet, S, f, x, ehs, pose):
+        dev = x.device
+        self.unet, self.S, self.f = unet, S, f
+        self.x = torch.empty((S * f,) + tuple(x.shape[1:]), dtype=x.dtype, device=dev)
+        self.temb = torch.zeros((S, unet.config["block_out_channels"][0]), dtype=torch.float32, device=dev)
+        self.ehs = torch.empty_like(ehs)
+        self.pose = None if pose is None else [torch.empty_like(p) for p in pose]
+        self.graph = None
+        self.pred = None
+
+    def matches(self, x, ehs, pose):
+        return (tuple(self.x.shape[1:]) == tuple(x.shape[1:]) and self.ehs.shape == ehs.shape and
+                self.ehs.dtype == ehs.dtype and (self.pose is None) == (pose is None) and
+                (pose is None or all(a.shape == b.shape for a, b in zip(self.pose, pose))))
+
+    def set_clip(self, ehs):
+        self.ehs.copy_(ehs)
+
+    def set_pose(self, pose):
+        if pose is not None:
+            for dst, src in zip(self.pose, pose):
+                dst.copy_(src)
+
+    def _fill_x(self, x):
+        for s_ in range(self.S):
+            self.x[s_ * self.f:(s_ + 1) * self.f].copy_(x)
+
+    def eager(self, x, temb):
+        self._fill_x(x)
+        self.temb.copy_(temb)
+        return self.unet.forward_nhwc(self.x, self.S, self.f, None, self.ehs, self.pose, temb_in=self.temb)
+
+    def replay(self, x, temb):
+        self._fill_x(x)
+        self.temb.copy_(temb)
+        if self.graph is None:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.pred = self.unet.forward_nhwc(self.x, self.S, self.f, None, self.ehs, self.pose,
+                                                   temb_in=self.temb)
+            self.graph = g
+        self.graph.replay()
+        return self.pred
 
 
 class Pose2VideoPipelineOutput(BaseOutput):
@@ -204,6 +282,16 @@ class Pose2VideoPipeline:
         a_p = float(sch.alphas_cumprod[prev]) if prev >= 0 else float(sch.final_alpha_cumprod)
         return math.sqrt(a_t), math.sqrt(max(1 - a_t, 0.0)), math.sqrt(a_p), math.sqrt(max(1 - a_p, 0.0))
 
+    def _get_runners(self):
+        """{(S, f, h, w, device): _DenoiseRunner} — dropped whenever the denoising UNet re-packs its weights
+        (a captured graph has the packed tensors' addresses baked in)."""
+        unet = self.denoising_unet
+        tag = (id(unet), id(unet.packed()))
+        if self.__dict__.get("_runner_tag") != tag:
+            self.__dict__["_runner_tag"] = tag
+            self.__dict__["_runners"] = {}
+        return self.__dict__["_runners"]
+
     @staticmethod
     def _require_gpu(device):
         if device.type != "cuda":
@@ -213,9 +301,10 @@ class Pose2VideoPipeline:
     @torch.no_grad()
     def _run(self, ref_image, pose_images, ref_pose_image, width, height, video_length, num_inference_steps,
              guidance_scale, num_images_per_prompt, eta, generator, output_type, return_dict, callback, callback_steps,
-             windows_fn, latents=None, dp_group=None, decode_chunk=16, return_latents=False):
+             windows_fn, latents=None, dp_group=None, decode_chunk=16, return_latents=False, use_graph=True):
         device = self._execution_device
         self._require_gpu(device)
+        tm = _StageTimer()
         if num_images_per_prompt != 1:
             raise NotImplementedError("num_images_per_prompt != 1")
         if eta != 0.0:
@@ -237,6 +326,7 @@ class Pose2VideoPipeline:
         if do_cfg:
             ehs = torch.cat([torch.zeros_like(ehs), ehs], dim=0)
         ehs = ehs.contiguous()
+        tm.mark("clip")
 
         writer = ReferenceAttentionControl(self.reference_unet, do_classifier_free_guidance=do_cfg, mode="write",
                                            batch_size=1, fusion_blocks="full")
@@ -259,13 +349,22 @@ class Pose2VideoPipeline:
         ref_t = self.ref_image_processor.preprocess(ref_image, height=height, width=width).to(device)
         ref_lat = vae.encode_mean_nhwc(ops.ncfhw_to_nhwc(ref_t.float().unsqueeze(2).contiguous()))
         ref_lat = (ref_lat.float() * 0.18215).half()                 # (1, h, w, 4)
+        tm.mark("latents+vae_encode")
 
         # pose condition images (numpy path of VaeImageProcessor: values in [-1, 509], see image_processor.py)
         pg = self.pose_guider
-        pose = torch.cat([self.cond_image_processor.preprocess(p, height=height, width=width).unsqueeze(2)
-                          for p in pose_images], dim=2).to(device=device, dtype=pg.dtype)
-        ref_pose = self.cond_image_processor.preprocess(ref_pose_image, height=height, width=width)
-        ref_pose = ref_pose.to(device=device, dtype=pg.dtype)
+        hp, wp = height - height % self.vae_scale_factor, width - width % self.vae_scale_factor
+        if all(isinstance(p, np.ndarray) and p.dtype == np.uint8 and p.shape == (hp, wp, 3) for p in pose_images):
+            # renderings already at the target size (scripts/pose2vid.py:158 resizes them): upload the bytes once;
+            # (L, H, W, 3) uint8 is the channels-last frame batch, 2 v - 1 is applied on the device
+            pose_nhwc = ops.u8_to_f16(torch.from_numpy(np.stack(pose_images)).to(device), 2.0, -1.0)
+        else:
+            pose = torch.cat([self.cond_image_processor.preprocess(p, height=height, width=width).unsqueeze(2)
+                              for p in pose_images], dim=2).to(device=device, dtype=pg.dtype)
+            pose_nhwc = ops.ncfhw_to_nhwc(pose)
+        # ref_pose_image only feeds PoseGuider's second argument, which never reaches the arithmetic
+        # (pose_guider.py: cross_attention_dim=None => no attn2): it is not preprocessed
+        tm.mark("pose_preprocess")
 
         # ReferenceNet: one pass at t = 0 (pipeline_pose2vid_long.py:474-485); only the banks matter, so
         # the pass stops after the last bank write.  With a dp_group, rank 0 computes and broadcasts.
@@ -275,6 +374,7 @@ class Pose2VideoPipeline:
         if ws > 1:
             self._broadcast_banks(writer, S, h, w, dp_group, device)
         reader.update(writer)
+        tm.mark("refnet")
 
         windows = [list(c) for c in windows_fn(L, num_inference_steps)]
         my_windows = D.shard_round_robin(len(windows), rank, ws) if ws > 1 else list(range(len(windows)))
@@ -286,13 +386,40 @@ class Pose2VideoPipeline:
                 c = windows[k]
                 # batch 1: the CFG duplication does not change train-mode BatchNorm statistics; ref_pose never
                 # reaches the arithmetic (pose_guider.py: cross_attention_dim=None => no attn2)
-                fea = pg.forward_nhwc(ops.ncfhw_to_nhwc(pose[:, :, c].contiguous()))
+                fea = pg.forward_nhwc(pose_nhwc if (pose_nhwc.shape[0] == L and c == list(range(L))) else
+                                      pose_nhwc[torch.tensor(c, dtype=torch.long, device=device)])
                 pose_cache[k] = [n.repeat(S, 1, 1, 1).contiguous() if S > 1 else n for n in fea]
             return pose_cache[k]
 
         acc = torch.empty((S, L, HWC), dtype=torch.float32, device=device)
         counter = torch.empty((L,), dtype=torch.float32, device=device)
         single = len(windows) == 1 and windows[0] == list(range(L))
+        # Denoising UNet forwards run through a persistent _DenoiseRunner (static input buffers).  Step 0 is eager
+        # (it re-projects the reference banks / attn2 vectors in place); later steps replay the runner's hipGraph,
+        # captured once per window shape and reused across clips.
+        ucfg = self.denoising_unet.config
+        temb_table = torch.stack([engine.timestep_sinusoid(t, S, ucfg["block_out_channels"][0], "cpu",
+                                                           ucfg.get("flip_sin_to_cos", True), ucfg.get("freq_shift", 0))
+                                  for t in timesteps]).to(device)
+        use_graph = bool(use_graph) and device.type == "cuda" and ops._WORK is None
+        runners = self._get_runners()
+        clip_runners = {}
+
+        def runner_for(k):
+            c = windows[k]
+            key = (S, len(c), h, w, str(device))
+            r = clip_runners.get(key)
+            if r is None:
+                x0 = lat16[: len(c)]
+                r = runners.get(key)
+                if r is None or not r.matches(x0, ehs[:S], pose_features(k)):
+                    r = runners[key] = _DenoiseRunner(self.denoising_unet, S, len(c), x0, ehs[:S], pose_features(k))
+                r.set_clip(ehs[:S])
+                if single:
+                    r.set_pose(pose_features(k))
+                clip_runners[key] = r
+            return r
+
         with self.progress_bar(total=num_inference_steps) as bar:
             for i, t in enumerate(timesteps):
                 acc.zero_()
@@ -300,8 +427,12 @@ class Pose2VideoPipeline:
                 for k in my_windows:
                     c = windows[k]
                     x = lat16 if single else lat16[win_idx[k].long()]
-                    x = x.repeat(S, 1, 1, 1).contiguous() if S > 1 else x
-                    pred = self.denoising_unet.forward_nhwc(x, S, len(c), t, ehs[:S], pose_features(k))
+                    r = runner_for(k)
+                    if not single:
+                        r.set_pose(pose_features(k))
+                    pred = r.replay(x, temb_table[i]) if (use_graph and i >= 1) else r.eager(x, temb_table[i])
+                    if i <= 1:
+                        tm.mark(f"unet_step{i}" + ("(eager)" if not (use_graph and i >= 1) else "(graph)"))
                     ops.window_accumulate(pred, acc, counter, win_idx[k], S, len(c), L, HWC)
                 if ws > 1 and len(windows) > 1:
                     D.allreduce_window_sums(acc, counter, dp_group)
@@ -312,6 +443,7 @@ class Pose2VideoPipeline:
                     callback(i, t, lat32.reshape(1, L, h, w, C).permute(0, 4, 1, 2, 3).contiguous())
         reader.clear()
         writer.clear()
+        tm.mark("unet_steps2+")
 
         final = lat32.reshape(1, L, h, w, C).permute(0, 4, 1, 2, 3).contiguous()
         if return_latents:
@@ -327,9 +459,12 @@ class Pose2VideoPipeline:
             video = self._decode_nhwc(z, 1, decode_chunk)
         if video is None:
             return None
+        tm.mark("vae_decode")
         images = video.cpu().float().numpy()
         if output_type == "tensor":
             images = torch.from_numpy(images)
+        tm.mark("d2h+float")
+        tm.report()
         if not return_dict:
             return images
         return Pose2VideoPipelineOutput(videos=images)

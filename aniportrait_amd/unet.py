@@ -42,8 +42,8 @@ class _RefBlock:
     def engine_state(self):
         st = self.state
         bank = self.node.bank[0] if (st.mode == "read" and len(self.node.bank) > 0) else None
-        if bank is not st.bank:  # bank replaced / cleared: drop the projected K/V
-            st.bank, st.kref, st.vtref = bank, None, None
+        if bank is not st.bank:  # bank replaced / cleared: K_ref / V_ref^T are re-projected (in place) on next use
+            st.bank, st.stale = bank, True
         return st
 
 
@@ -100,14 +100,19 @@ class _UNetBase(HipModel):
         src/models/mutual_self_attention.py:77-85,148-186"""
         if not any(r.mode == "read" and r.bank is not None for r in refs.values()):
             return None
+        nb = next(r.bank.shape[0] for r in refs.values() if r.mode == "read" and r.bank is not None)
+        key = (b, f, bool(self._ref_cfg), nb, str(device))
+        cache = self.__dict__.setdefault("_ref_index_cache", {})
+        if key in cache:                       # no host->device copy in steady state (hipGraph-capturable)
+            return cache[key]
         N = b * f
         idx = torch.arange(N, dtype=torch.int32) // f
         if self._ref_cfg:
             idx[: N // 2] = -1
-        nb = next(r.bank.shape[0] for r in refs.values() if r.mode == "read" and r.bank is not None)
         if int(idx.max()) >= nb:
             raise ValueError(f"reference bank holds {nb} sample(s) but the batch addresses sample {int(idx.max())}")
-        return idx.to(device), int((idx >= 0).sum())
+        cache[key] = (idx.to(device), int((idx >= 0).sum()))
+        return cache[key]
 
     def _check_unsupported(self, **kw):
         for k, v in kw.items():
@@ -115,13 +120,14 @@ class _UNetBase(HipModel):
                 raise NotImplementedError(f"{type(self).__name__}.forward: `{k}` is not part of the pose2vid hot path")
 
     def forward_nhwc(self, x, b, f, timestep, encoder_hidden_states, pose_nhwc=None, final=True,
-                     stop_after_last_bank=False):
-        """channels-last entry used by the pipeline: x (b*f, h, w, C) fp16 on the GPU."""
+                     stop_after_last_bank=False, temb_in=None):
+        """channels-last entry used by the pipeline: x (b*f, h, w, C) fp16 on the GPU.  temb_in: device fp32
+        (b, C0) timestep sinusoid replacing `timestep` (see engine.unet_forward)."""
         net = self.packed()
         refs = self._engine_refs()
         ridx = self._ref_index(b, f, refs, net.device)
         out = engine.unet_forward(net, self.config, x, b, f, timestep, encoder_hidden_states, self._attn2_cache,
-                                  refs, self.three_d, ridx, pose_nhwc, final, stop_after_last_bank)
+                                  refs, self.three_d, ridx, pose_nhwc, final, stop_after_last_bank, temb_in)
         for p, rb in self._ref_blocks.items():  # write mode: append to module.bank like the hacked forward
             if rb.state.mode == "write" and rb.state.written is not None:
                 rb.node.bank.append(rb.state.written)

@@ -155,6 +155,11 @@ int anip_ncfhw_to_nhwc(const void* src, int src_f32, void* dst, int B, int C, in
 int anip_nhwc_to_ncfhw(const void* src, void* dst, int dst_f32, int B, int C, int F, int64_t HW, float scale,
                        float shift, int clamp01, void* stream);
 
+/* dst[i] = (fp16)(scale * src[i] + shift), src uint8: the numpy path of VaeImageProcessor.preprocess on the pose
+ * renderings (src/pipelines/pipeline_pose2vid_long.py:445-452: values 2 v - 1 in [-1, 509], no /255), done on
+ * the device on the uploaded bytes; (L,H,W,3) uint8 is already the channels-last frame batch. */
+int anip_u8_to_f16(const void* src, void* dst, int64_t n, float scale, float shift, void* stream);
+
 /* ---- per-kernel timing with HIP events (bench.py's roofline leg) -------------------------------------
  * When enabled, every entry point brackets each kernel launch with hipEventRecord on the launch stream.
  * anip_profile_collect synchronises, sums elapsed time and launch count per kernel family

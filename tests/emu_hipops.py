@@ -162,10 +162,14 @@ def softmax_rows(s):
     return torch.softmax(s.float(), dim=-1).to(F16)
 
 
-def linear_small(x, W, bias=None, silu_in=False):
+def linear_small(x, W, bias=None, silu_in=False, out=None):
     xx = F.silu(x.float()) if silu_in else x.float()
     y = xx @ W.float().t()
-    return y + bias.float() if bias is not None else y
+    y = y + bias.float() if bias is not None else y
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
 
 
 def add(a, b):
@@ -208,9 +212,13 @@ def nhwc_to_ncfhw(src, B, out_f32=False, scale=1.0, shift=0.0, clamp01=False):
     return y.contiguous() if out_f32 else y.to(F16).contiguous()
 
 
+def u8_to_f16(src, scale=1.0, shift=0.0):
+    return (src.float() * scale + shift).to(F16)
+
+
 _EMULATED = ("groupnorm", "layernorm", "gemm", "conv3x3", "conv_small", "conv_direct", "batchnorm", "ref_attention",
              "temporal_attention", "softmax_rows", "linear_small", "add", "window_accumulate", "cfg_ddim_step",
-             "ncfhw_to_nhwc", "nhwc_to_ncfhw")
+             "ncfhw_to_nhwc", "nhwc_to_ncfhw", "u8_to_f16")
 
 
 def install(monkeypatch):

@@ -565,3 +565,12 @@ def test_batchnorm_large_offset():
     y = ops.batchnorm(x.to(DEV), g.to(DEV), b.to(DEV), None, None, 1e-5, False)
     ref = F.batch_norm(x.double(), None, None, g.double(), b.double(), training=True, eps=1e-5)
     close(y, ref, "batchnorm offset", rtol=4e-3, arms=4e-3)
+
+
+def test_u8_to_f16():
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    for n in (8 * 1000, 8 * 1000 + 5, 3):
+        src = torch.randint(0, 256, (n,), generator=g, dtype=torch.uint8)
+        out = ops.u8_to_f16(src.to(DEV), 2.0, -1.0)
+        assert torch.equal(out.cpu(), (src.float() * 2 - 1).half())
