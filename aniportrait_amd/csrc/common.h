@@ -63,5 +63,16 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf-GELU for GEMM epilogues (VALU-bound there): erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below
+// the fp16 rounding of the result), branch-free, one v_rcp + one v_exp; for x < 0 the factor 1 + erf is formed
+// as poly * exp directly, so the tail keeps its relative accuracy.
+__device__ __forceinline__ float gelu_fast_f(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+  const float pe = poly * __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
+  const float one_plus_erf = x >= 0.f ? 2.0f - pe : pe;
+  return 0.5f * x * one_plus_erf;
+}
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

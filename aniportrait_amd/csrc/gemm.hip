@@ -212,16 +212,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_small_kernel(const anip_gemm
       int ncol;        // first output column of this chunk
       int nvalid;      // number of valid output columns in the chunk
       if (geglu) {
-        const float* hrow = cs + row * CS + cc * 8;
-        const float* grow = hrow + 64;
-        const int pn = n0 + cc * 8;  // packed column of h; gate at +64
+        // packed columns per 32: [16 x value | 16 x gate]; output chunk cc = output columns cc*8..+7 of the tile
+        const int pc = (cc >> 1) * 32 + (cc & 1) * 8;
+        const float* hrow = cs + row * CS + pc;
+        const float* grow = hrow + 16;
+        const int pn = n0 + pc;      // packed column of the value; gate at +16
         ncol = bn * 64 + cc * 8;
         nvalid = min(8, p.N / 2 - ncol);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float hh = hrow[e], gg = grow[e];
-          if (p.bias != nullptr && e < nvalid) { hh += p.bias[pn + e]; gg += p.bias[pn + 64 + e]; }
-          v[e] = hh * gelu_erf_f(gg);
+          if (p.bias != nullptr && e < nvalid) { hh += p.bias[pn + e]; gg += p.bias[pn + 16 + e]; }
+          v[e] = hh * gelu_fast_f(gg);
         }
       } else {
         const float* crow = cs + row * CS + cc * 8;
@@ -305,7 +307,7 @@ extern "C" int anip_gemm(const anip_gemm_params* pp, void* stream) {
   if (p.alpha == 0.0f) p.alpha = 1.0f;
   if (p.rowbias != nullptr) ANIP_REQUIRE(p.rows_per_group > 0, "anip_gemm: rows_per_group must be > 0");
   if (p.act == 1) {
-    ANIP_REQUIRE((p.N % 128) == 0, "anip_gemm: GEGLU needs N %% 128 == 0 (N=%d)", p.N);
+    ANIP_REQUIRE((p.N % 128) == 0, "anip_gemm: GEGLU needs N %% 128 == 0 (N=%d)", p.N);  // whole 32-column [v|g] groups per tile
     ANIP_REQUIRE(p.residual == nullptr && p.rowbias == nullptr, "anip_gemm: GEGLU excludes residual/rowbias");
   }
   if (p.conv) {

@@ -15,37 +15,71 @@
 //    barrier stalls overlap the other's MFMAs.
 //  * A operand loaders: plain row-major (optionally two sources split along K = fused channel concat),
 //    or NHWC 3x3 window gather (stride 1/2, zero padding, fused nearest-2x upsample).
-//  * epilogue through fp32 LDS staging in 64-row passes, 16-B coalesced stores: bias, per-row-group
-//    bias, GEGLU, residual, fp32 out, transposed out (V^T projection), single rounding to fp16.
+//  * epilogue straight from the accumulators, no LDS staging and no barriers: the MFMA is issued with the
+//    operands swapped (C^T tiles), so a lane holds 4 consecutive output columns of one row; one
+//    v_permlane16_swap per dword between two neighbouring 16-column tiles widens that to 8 consecutive
+//    columns = one 16-B store / residual load per lane.  Fused: bias, per-row-group bias, GEGLU (value and
+//    gate tiles of one output column sit in the same lane: weights packed per 32 columns as [16 v | 16 g]),
+//    residual, fp32 out; the transposed-out variant (V^T projection) keeps the un-swapped operand order and
+//    pairs tiles along M instead.  Single rounding to fp16.
 //  * XCD-aware bijective tile order: each XCD's private L2 sees a contiguous run of tiles sharing A panels.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
-constexpr int BK2 = 32;
-constexpr int RB = BK2 * 2;      // LDS row bytes
-constexpr int RPI = 1024 / RB;   // rows per LDS-DMA instruction (16)
 constexpr uint32_t OOB = 0xFFFFFFF0u;
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-__device__ __forceinline__ int swz_of(int row) { return ((row >> 3) & 1) * 2; }
+// bank swizzle of the 16-B chunk index inside an LDS row (applied on the DMA SOURCE address and on the
+// ds_read_b128 side; the DMA destination is lane-linear):
+//   64-B rows (BK = 32, 4 chunks): chunk ^= 2 * bit3(row);  128-B rows (BK = 64, 8 chunks): chunk ^= row & 7
+template <int BKT>
+__device__ __forceinline__ int swz_of(int row) {
+  return BKT == 32 ? ((row >> 3) & 1) * 2 : (row & 7);
+}
 
-// BM2 = 256 (8 waves, 2 blocks per CU) for problems with >= ~1000 tiles, BM2 = 128 (4 waves, up to 3 blocks
-// per CU) to double the tile count of smaller problems.
-template <int BM2, int BN, bool CONV>
-__global__ __launch_bounds__(BM2 * 2, (BM2 == 256 ? 4 : 2)) void gemm2_kernel(const anip_gemm_params p) {
-  constexpr int NT2 = BM2 * 2;                 // threads: one wave per 32 tile rows
-  constexpr int NW = NT2 / 64;                 // waves, arranged (BM2/64) along M x 2 along N
-  constexpr int NB = BN / 32;                  // 16-col MFMA tiles per wave along N
+// rows of 16 lanes: swap the odd rows of x with the even rows of y (v_permlane16_swap).  Afterwards, for two
+// tiles X, Y whose lanes (row fq) each held columns fq*4..+3:  lanes of even rows hold tile X columns
+// (fq/2)*8..+7 as [x, y], lanes of odd rows hold tile Y columns (fq/2)*8..+7 as [x, y].
+__device__ __forceinline__ void row_swap(float& x, float& y) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  x = __uint_as_float(r[0]);
+  y = __uint_as_float(r[1]);
+}
+
+// Tile configurations (BM2 x BN x BKT, NW waves arranged (NW/WNW) x WNW):
+//   256 x {128,160} x 32, 8 waves 4x2, 3-stage ring, 2 blocks/CU  — many short-K tiles
+//   128 x {128,160} x 32, 4 waves 2x2, 3-stage ring, up to 3 blocks/CU — small problems
+//   256 x {256,320} x 64, 8 waves 2x4 (wave tile 128 x {64,80}), 2-stage, 1 block/CU — the global->LDS traffic per
+//     flop drops by 1/4..1/3 and every DMA row is a full 128-B line (BK = 32 rows are half lines), which is what
+//     bounds the smaller tiles (measured: DMA alone = 0.93 ms of the 1.18 ms 8192^3 GEMM).
+template <int BM2, int BN, int NW, int WNW, int BKT, int NST, bool CONV, bool TRANS>
+__global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void gemm2_kernel(const anip_gemm_params p,
+                                                                                           const int dbg) {
+  constexpr int NT2 = NW * 64;
+  constexpr int RB = BKT * 2;                  // LDS row bytes
+  constexpr int CPR = RB / 16;                 // 16-B chunks per row
+  constexpr int RPI = 1024 / RB;               // rows per LDS-DMA instruction
+  // NST = ring depth.  With NST >= 4 the barrier of iteration kt also covers the landing of tile kt+1 (LAND = 1),
+  // so the first fragments of tile kt+1 are fetched at the end of iteration kt and the MFMAs of the next
+  // iteration start right after its barrier.
+  constexpr int LAND = NST >= 4 ? 1 : 0;
+  constexpr int KH = BKT / 32;                 // 32-deep MFMA steps per K-tile
+  constexpr int WMW = NW / WNW;                // waves along M
+  constexpr int WTM = BM2 / WMW, WTN = BN / WNW;  // wave tile
+  constexpr int FM = WTM / 16, NB = WTN / 16;  // 16x16 MFMA tiles per wave along M / N
   constexpr int A_BYTES = BM2 * RB, B_BYTES = BN * RB, STAGE = A_BYTES + B_BYTES;
-  constexpr int NA_I = BM2 / RPI / NW;         // A DMA instructions per wave per K-tile (2)
-  constexpr int NB_TOT = BN / RPI;             // B DMA instructions per K-tile (8 or 10)
+  constexpr int NA_I = BM2 / RPI / NW;         // A DMA instructions per wave per K-tile
+  constexpr int NB_TOT = BN / RPI;             // B DMA instructions per K-tile
   constexpr int NB_I = (NB_TOT + NW - 1) / NW; // max per wave
+  static_assert(BM2 % (RPI * NW) == 0 && WTM % 16 == 0 && WTN % 16 == 0 && (FM % 2) == 0, "bad tile configuration");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WNW, wn = wave % WNW;
 
   const int nbm = (p.M + BM2 - 1) / BM2, nbn = (p.N + BN - 1) / BN, nblk = nbm * nbn;
   int swz;
@@ -73,7 +107,7 @@ __global__ __launch_bounds__(BM2 * 2, (BM2 == 256 ? 4 : 2)) void gemm2_kernel(co
   auto rW = __builtin_amdgcn_make_buffer_rsrc((void*)Wp, 0, w_bytes, 0x00020000);
 
   // ---- per-lane DMA source bookkeeping ------------------------------------------------------------
-  const int lr = lane >> 2, ls = lane & 3;     // row within the 16-row DMA group, 16-B slot within the row
+  const int lr = lane / CPR, ls = lane % CPR;  // row within the DMA instruction's row group, 16-B slot within the row
   uint32_t a_off[NA_I];                        // plain: byte offset of (row, chunk g) at k = 0; conv: pixel base
   int a_g[NA_I];
   int a_y0[NA_I], a_x0[NA_I];
@@ -81,7 +115,7 @@ __global__ __launch_bounds__(BM2 * 2, (BM2 == 256 ? 4 : 2)) void gemm2_kernel(co
 #pragma unroll
   for (int i = 0; i < NA_I; ++i) {
     const int row = (wave * NA_I + i) * RPI + lr;
-    const int g = ls ^ swz_of(row);
+    const int g = ls ^ swz_of<BKT>(row);
     const int m = m0 + row;
     a_g[i] = g;
     a_ok[i] = m < p.M;
@@ -103,19 +137,20 @@ __global__ __launch_bounds__(BM2 * 2, (BM2 == 256 ? 4 : 2)) void gemm2_kernel(co
   for (int i = 0; i < NB_I; ++i) {
     const int j = wave + NW * i;
     const int row = j * RPI + lr;
-    const int g = ls ^ swz_of(row);
+    const int g = ls ^ swz_of<BKT>(row);
     const int n = n0 + row;
     b_off[i] = (j < NB_TOT && n < p.N) ? (uint32_t)(((int64_t)n * p.ldw + g * 8) * 2) : OOB;
   }
   const int my_b = (NB_TOT - wave + NW - 1) / NW;  // B DMA instructions this wave issues (wave-uniform)
 
   auto issue = [&](int kt, int stage) {
+    if (dbg & 2) return;   // experiment: no global->LDS traffic
     char* sa = smem + stage * STAGE;
     char* sb = sa + A_BYTES;
-    const int k0 = kt * BK2;
-    const bool ktail = k0 + BK2 > p.K;         // wave-uniform
+    const int k0 = kt * BKT;
+    const bool ktail = k0 + BKT > p.K;         // wave-uniform
     if (CONV) {
-      const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;   // tap uniform over the K-tile (Cin % 32 == 0)
+      const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;   // tap uniform over the K-tile (Cin % BKT == 0)
       const int dy = tap / 3, dx = tap - dy * 3;
       const int He = p.upsample ? 2 * p.Hin : p.Hin, We = p.upsample ? 2 * p.Win : p.Win;
 #pragma unroll
@@ -127,7 +162,7 @@ __global__ __launch_bounds__(BM2 * 2, (BM2 == 256 ? 4 : 2)) void gemm2_kernel(co
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(sa + (wave * NA_I + i) * 1024), 16, vo, 0, 0, 0);
       }
     } else {
-      const bool second = (p.A2 != nullptr) && (k0 >= p.K1);   // wave-uniform (K1 % 32 == 0)
+      const bool second = (p.A2 != nullptr) && (k0 >= p.K1);   // wave-uniform (K1 % BKT == 0)
       const int kk = second ? k0 - p.K1 : k0;
       const int64_t ld = second ? p.lda2 : p.lda;
       const int klim = second ? p.K - p.K1 : (p.A2 ? p.K1 : p.K);
@@ -145,7 +180,7 @@ __global__ __launch_bounds__(BM2 * 2, (BM2 == 256 ? 4 : 2)) void gemm2_kernel(co
         uint32_t vo = b_off[i];
         if (ktail) {
           const int row = (wave + NW * i) * RPI + lr;
-          if (k0 + (ls ^ swz_of(row)) * 8 >= p.K) vo = OOB;
+          if (k0 + (ls ^ swz_of<BKT>(row)) * 8 >= p.K) vo = OOB;
         }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(sb + (wave + NW * i) * 1024), 16, vo, (uint32_t)k0 * 2u, 0, 0);
       }
@@ -154,196 +189,307 @@ __global__ __launch_bounds__(BM2 * 2, (BM2 == 256 ? 4 : 2)) void gemm2_kernel(co
 
   // ---- fragment read offsets ------------------------------------------------------------------------
   const int fr = lane & 15, fq = lane >> 4;
-  const int koff = (fq ^ swz_of(fr)) << 4;
-  const int a_row_off = (wm * 64 + fr) * RB + koff;
-  const int b_row_off = (wn * (BN / 2) + fr) * RB + koff;
-
-  f32x4 acc[4][NB];
+  int koff[KH];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int kh = 0; kh < KH; ++kh) koff[kh] = ((kh * 4 + fq) ^ swz_of<BKT>(fr)) << 4;
+  const int a_row_off = (wm * WTM + fr) * RB;
+  const int b_row_off = (wn * WTN + fr) * RB;
+
+  f32x4 acc[FM][NB];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.K + BK2 - 1) / BK2;
-  issue(0, 0);
-  if (nk > 1) issue(1, 1);
+  const int nk = (p.K + BKT - 1) / BKT;
+#pragma unroll
+  for (int t = 0; t < NST - 1; ++t)
+    if (t < nk) issue(t, t);
+  f16x8 bfn[NB];   // LAND: prefetched B fragments / first A fragment of the next K-tile (k-half 0)
+  f16x8 afn;
   for (int kt = 0; kt < nk; ++kt) {
-    // this wave's part of tile kt has landed; leave only tile kt+1's DMA in flight
-    if (kt + 1 < nk) {
-      if (my_b == NB_I) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA_I + NB_I) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA_I + NB_I - 1) : "memory");
+    // this wave's parts of tiles kt .. kt+LAND have landed; later tiles (if any were issued) stay in flight
+    if (NST - 2 - LAND > 0 && kt + LAND + 1 < nk) {
+      if (my_b == NB_I) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2 - LAND) * (NA_I + NB_I)) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2 - LAND) * (NA_I + NB_I - 1)) : "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();  // tile kt complete for all waves; stage (kt+2)%3 no longer being read
-    if (kt + 2 < nk) issue(kt + 2, (kt + 2) % 3);
-    const char* sa = smem + (kt % 3) * STAGE;
+    __builtin_amdgcn_s_barrier();  // those tiles are complete for all waves; the stage read at kt-1 is free
+    if (kt + NST - 1 < nk) issue(kt + NST - 1, (kt + NST - 1) % NST);
+    const char* sa = smem + (kt % NST) * STAGE;
     const char* sb = sa + A_BYTES;
-    f16x8 af[4], bf[NB];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) af[t] = *(const f16x8*)(sa + a_row_off + t * 16 * RB);
+    for (int kh = 0; kh < KH; ++kh) {
+      f16x8 bf[NB];
+      const bool pre = LAND && kh == 0 && kt > 0;   // fragments fetched at the end of the previous iteration
 #pragma unroll
-    for (int t = 0; t < NB; ++t) bf[t] = *(const f16x8*)(sb + b_row_off + t * 16 * RB);
+      for (int t = 0; t < NB; ++t) bf[t] = pre ? bfn[t] : *(const f16x8*)(sb + b_row_off + t * 16 * RB + koff[kh]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < FM; ++i) {
+        const f16x8 af = (pre && i == 0) ? afn : *(const f16x8*)(sa + a_row_off + i * 16 * RB + koff[kh]);
+        if (!(dbg & 4))      // experiment: no MFMAs
 #pragma unroll
-      for (int j = 0; j < NB; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NB; ++j)
+            acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0)
+                              : __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af, acc[i][j], 0, 0, 0);
+      }
+    }
+    if (LAND && kt + 1 < nk) {
+      const char* na = smem + ((kt + 1) % NST) * STAGE;
+      const char* nb_ = na + A_BYTES;
+#pragma unroll
+      for (int t = 0; t < NB; ++t) bfn[t] = *(const f16x8*)(nb_ + b_row_off + t * 16 * RB + koff[0]);
+      afn = *(const f16x8*)(na + a_row_off + koff[0]);
+    }
   }
 
-  // ---- epilogue: passes of 64 rows through an fp32 LDS staging tile ---------------------------------
-  constexpr int CS = BN + 4;
-  float* cs = (float*)smem;
+  // ---- epilogue: straight from the accumulators ------------------------------------------------------
+  //   !TRANS: acc[i][j][r] = C[m0 + wm*WTM + i*16 + fr][n0 + wn*WTN + j*16 + fq*4 + r]
+  //    TRANS: acc[i][j][r] = C[m0 + wm*WTM + i*16 + fq*4 + r][n0 + wn*WTN + j*16 + fr]
+  if (dbg & 1) {           // experiment: no epilogue (keep the accumulators live)
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) asm volatile("" ::"v"(acc[i][j]));
+    return;
+  }
   const float alpha = p.alpha;
-  const bool geglu = p.act == 1;
   const int64_t obatch = (p.batch > 1) ? (int64_t)blockIdx.y * p.strideO : 0;
-  for (int pass = 0; pass < BM2 / 64; ++pass) {
-    __builtin_amdgcn_s_barrier();  // readers of this LDS region (K loop / previous pass) are done
-    if (wm == pass) {
+  const int tsel = fq & 1, csel = (fq >> 1) * 8;   // after row_swap: tile of the pair / column offset in it
+
+  // 8 consecutive output columns [n, n+8) of row m: bias / row-group bias / residual / store
+  auto emit8 = [&](int m, int n, int ncols, float (&v)[8], bool with_bias) {
+    if (m >= p.M) return;
+    const int nvalid = min(8, ncols - n);
+    if (nvalid <= 0) return;
+    if (with_bias && p.bias != nullptr) {
+      if (nvalid == 8) {
+        const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+      } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            cs[(i * 16 + fq * 4 + r) * CS + wn * (BN / 2) + j * 16 + fr] = acc[i][j][r] * alpha;
+        for (int e = 0; e < 8; ++e)
+          if (e < nvalid) v[e] += p.bias[n + e];
+      }
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    const int mbase = m0 + pass * 64;
-    if (p.trans_out) {
-      // out[n][m]: thread -> (column n, 8 consecutive rows)
-      constexpr int CPS = NT2 / BN;            // 8-row chunks per sweep (4 or 3)
-      const int n = tid % BN, ch0 = tid / BN;
-      if (ch0 < CPS && n0 + n < p.N) {
-        const float bn_ = p.bias ? p.bias[n0 + n] : 0.f;
-        for (int ch = ch0; ch < 8; ch += CPS) {
-          const int m = mbase + ch * 8;
-          if (m >= p.M) break;
-          float v[8];
+    if (with_bias && p.rowbias != nullptr) {
+      const float* rbp = p.rowbias + ((int64_t)m / p.rows_per_group) * p.ld_rowbias + n;
+      if (nvalid == 8 && ((p.ld_rowbias & 3) == 0) && (((uintptr_t)p.rowbias & 15) == 0)) {
+        const float4 b0 = *(const float4*)rbp, b1 = *(const float4*)(rbp + 4);
+        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+      } else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = cs[(ch * 8 + e) * CS + n] + bn_;
-          f16* op = (f16*)p.out + obatch + (int64_t)(n0 + n) * p.ldo + m;
+        for (int e = 0; e < 8; ++e)
+          if (e < nvalid) v[e] += rbp[e];
+      }
+    }
+    if (with_bias && p.residual != nullptr) {
+      const f16* rp = (const f16*)p.residual + (int64_t)m * p.ldr + n;
+      if (nvalid == 8 && ((p.ldr & 7) == 0)) {
+        U4H8 t;
+        t.u = *(const u32x4*)rp;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)t.e[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (e < nvalid) v[e] += (float)rp[e];
+      }
+    }
+    const int64_t o = obatch + (int64_t)m * p.ldo + n;
+    if (p.out_f32) {
+      float* op = (float*)p.out + o;
+      if (nvalid == 8 && ((p.ldo & 3) == 0)) {
+        *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (e < nvalid) op[e] = v[e];
+      }
+    } else {
+      f16* op = (f16*)p.out + o;
+      if (nvalid == 8 && ((p.ldo & 7) == 0)) {
+        U4H8 t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t.e[e] = (f16)v[e];
+        *(u32x4*)op = t.u;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (e < nvalid) op[e] = (f16)v[e];
+      }
+    }
+  };
+  // 4 consecutive output columns (the unpaired last tile when BN/32 is odd)
+  auto emit4 = [&](int m, int n, float (&v)[4]) {
+    if (m >= p.M) return;
+    const int nvalid = min(4, p.N - n);
+    if (nvalid <= 0) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (e < nvalid) {
+        if (p.bias != nullptr) v[e] += p.bias[n + e];
+        if (p.rowbias != nullptr) v[e] += p.rowbias[((int64_t)m / p.rows_per_group) * p.ld_rowbias + n + e];
+      }
+    }
+    if (p.residual != nullptr) {
+      const f16* rp = (const f16*)p.residual + (int64_t)m * p.ldr + n;
+      if (nvalid == 4 && ((p.ldr & 3) == 0)) {
+        union { u32x2 u; f16 e[4]; } t;
+        t.u = *(const u32x2*)rp;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)t.e[e];
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (e < nvalid) v[e] += (float)rp[e];
+      }
+    }
+    const int64_t o = obatch + (int64_t)m * p.ldo + n;
+    if (p.out_f32) {
+      float* op = (float*)p.out + o;
+      if (nvalid == 4 && ((p.ldo & 3) == 0)) *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
+      else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (e < nvalid) op[e] = v[e];
+      }
+    } else {
+      f16* op = (f16*)p.out + o;
+      if (nvalid == 4 && ((p.ldo & 3) == 0)) {
+        union { u32x2 u; f16 e[4]; } t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t.e[e] = (f16)v[e];
+        *(u32x2*)op = t.u;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (e < nvalid) op[e] = (f16)v[e];
+      }
+    }
+  };
+
+  if (TRANS) {
+    // out[n][m], m contiguous: pair the tiles (i, i+1) along M; bias only (checked by the launcher)
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int n = n0 + wn * WTN + j * 16 + fr;
+      const float bn_ = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int ip = 0; ip < FM / 2; ++ip) {
+        float x[4], y[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          x[r] = acc[2 * ip][j][r] * alpha + bn_;
+          y[r] = acc[2 * ip + 1][j][r] * alpha + bn_;
+          row_swap(x[r], y[r]);
+        }
+        const int m = m0 + wm * WTM + (2 * ip + tsel) * 16 + csel;
+        if (n < p.N && m < p.M) {
+          f16* op = (f16*)p.out + obatch + (int64_t)n * p.ldo + m;
           if (m + 8 <= p.M && ((p.ldo & 7) == 0)) {
             U4H8 t;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) t.e[e] = (f16)v[e];
+            for (int r = 0; r < 4; ++r) { t.e[r] = (f16)x[r]; t.e[4 + r] = (f16)y[r]; }
             *(u32x4*)op = t.u;
           } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-              if (m + e < p.M) op[e] = (f16)v[e];
+            for (int r = 0; r < 4; ++r) {
+              if (m + r < p.M) op[r] = (f16)x[r];
+              if (m + 4 + r < p.M) op[4 + r] = (f16)y[r];
+            }
           }
         }
       }
-    } else if (geglu) {
-      // packed columns per 128-tile: [64 x value | 64 x gate] -> 64 output columns
-      if (BN == 128) {
-        const int cc = tid & 7;
-        const int pn = n0 + cc * 8, ncol = bn * 64 + cc * 8;
-        for (int row = tid >> 3; row < 64; row += NT2 / 8) {
-        const int m = mbase + row;
-        if (m < p.M && ncol < p.N / 2) {
-          const float* hrow = cs + row * CS + cc * 8;
-          const float* grow = hrow + 64;
-          U4H8 t;
+    }
+  } else if (p.act == 1) {
+    // GEGLU: packed columns per 32 = [16 x value | 16 x gate] -> tiles (2t, 2t+1) of a wave are the value / gate
+    // of the same 16 output columns; out column = packed column / 2
+    if (NB == 4) {
+      const int pn = n0 + wn * WTN + fq * 4;          // packed column of acc[i][0][0]
+      float bv0[4], bg0[4], bv1[4], bg1[4];
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            float hh = hrow[e], gg = grow[e];
-            if (p.bias != nullptr) { hh += p.bias[pn + e]; gg += p.bias[pn + 64 + e]; }
-            t.e[e] = (f16)(hh * gelu_erf_f(gg));
-          }
-          f16* op = (f16*)p.out + obatch + (int64_t)m * p.ldo + ncol;
-          if ((p.ldo & 7) == 0) *(u32x4*)op = t.u;
-          else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) op[e] = t.e[e];
-          }
-        }
-        }
+      for (int r = 0; r < 4; ++r) {
+        const bool hb = p.bias != nullptr;
+        bv0[r] = (hb && pn + r < p.N) ? p.bias[pn + r] : 0.f;
+        bg0[r] = (hb && pn + 16 + r < p.N) ? p.bias[pn + 16 + r] : 0.f;
+        bv1[r] = (hb && pn + 32 + r < p.N) ? p.bias[pn + 32 + r] : 0.f;
+        bg1[r] = (hb && pn + 48 + r < p.N) ? p.bias[pn + 48 + r] : 0.f;
       }
-    } else {
-      constexpr int NCHUNK = BN / 8, RSTEP = NT2 / NCHUNK;
-      const int cc = tid % NCHUNK, r0 = tid / NCHUNK;
-      const int ncol = n0 + cc * 8;
-      const int nvalid = min(8, p.N - ncol);
-      if (r0 < RSTEP && nvalid > 0) {
-        float bv[8];
+      const int ocol = (n0 + wn * WTN) / 2 + tsel * 16 + csel;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) bv[e] = (p.bias != nullptr && e < nvalid) ? p.bias[ncol + e] : 0.f;
-        for (int r = r0; r < 64; r += RSTEP) {
-          const int m = mbase + r;
-          if (m >= p.M) break;
-          const float4 v0 = *(const float4*)(cs + r * CS + cc * 8), v1 = *(const float4*)(cs + r * CS + cc * 8 + 4);
-          float v[8] = {v0.x + bv[0], v0.y + bv[1], v0.z + bv[2], v0.w + bv[3],
-                        v1.x + bv[4], v1.y + bv[5], v1.z + bv[6], v1.w + bv[7]};
-          if (p.rowbias != nullptr) {
-            const float* rbp = p.rowbias + ((int64_t)m / p.rows_per_group) * p.ld_rowbias + ncol;
+      for (int i = 0; i < FM; ++i) {
+        float v[8];
 #pragma unroll
-            for (int e = 0; e < 8; ++e)
-              if (e < nvalid) v[e] += rbp[e];
-          }
-          if (p.residual != nullptr) {
-            const f16* rp = (const f16*)p.residual + (int64_t)m * p.ldr + ncol;
-            if (nvalid == 8 && ((p.ldr & 7) == 0)) {
-              U4H8 t;
-              t.u = *(const u32x4*)rp;
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += (float)t.e[e];
-            } else {
-#pragma unroll
-              for (int e = 0; e < 8; ++e)
-                if (e < nvalid) v[e] += (float)rp[e];
-            }
-          }
-          const int64_t o = obatch + (int64_t)m * p.ldo + ncol;
-          if (p.out_f32) {
-            float* op = (float*)p.out + o;
-            if (nvalid == 8 && ((p.ldo & 3) == 0)) {
-              *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
-              *(float4*)(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
-            } else {
-#pragma unroll
-              for (int e = 0; e < 8; ++e)
-                if (e < nvalid) op[e] = v[e];
-            }
-          } else {
-            f16* op = (f16*)p.out + o;
-            if (nvalid == 8 && ((p.ldo & 7) == 0)) {
-              U4H8 t;
-#pragma unroll
-              for (int e = 0; e < 8; ++e) t.e[e] = (f16)v[e];
-              *(u32x4*)op = t.u;
-            } else {
-#pragma unroll
-              for (int e = 0; e < 8; ++e)
-                if (e < nvalid) op[e] = (f16)v[e];
-            }
-          }
+        for (int r = 0; r < 4; ++r) {
+          float h0 = (acc[i][0][r] * alpha + bv0[r]) * gelu_fast_f(acc[i][1][r] * alpha + bg0[r]);
+          float h1 = (acc[i][2][r] * alpha + bv1[r]) * gelu_fast_f(acc[i][3][r] * alpha + bg1[r]);
+          row_swap(h0, h1);
+          v[r] = h0;
+          v[4 + r] = h1;
         }
+        emit8(m0 + wm * WTM + i * 16 + fr, ocol, p.N / 2, v, false);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int jp = 0; jp < NB / 2; ++jp) {
+      const int n = n0 + wn * WTN + (2 * jp + tsel) * 16 + csel;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = acc[i][2 * jp][r] * alpha, y = acc[i][2 * jp + 1][r] * alpha;
+          row_swap(x, y);
+          v[r] = x;
+          v[4 + r] = y;
+        }
+        emit8(m0 + wm * WTM + i * 16 + fr, n, p.N, v, true);
+      }
+    }
+    if (NB & 1) {
+      const int n = n0 + wn * WTN + (NB - 1) * 16 + fq * 4;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[i][NB - 1][r] * alpha;
+        emit4(m0 + wm * WTM + i * 16 + fr, n, v);
       }
     }
   }
 }
 
-template <int BM2, int BN, bool CONV>
+template <int BM2, int BN, int NW, int WNW, int BKT, int NST, bool CONV, bool TRANS>
 int launch_gemm2(const anip_gemm_params& p, hipStream_t stream) {
-  constexpr int NT2 = BM2 * 2;
-  constexpr int STAGE = (BM2 + BN) * RB;
-  constexpr int EPI = 64 * (BN + 4) * 4;
-  constexpr int LDS = (3 * STAGE > EPI) ? 3 * STAGE : EPI;
+  constexpr int NT2 = NW * 64;
+  constexpr int LDS = NST * (BM2 + BN) * BKT * 2;
   static bool attr_done = false;
   if (!attr_done) {
-    auto kfn = gemm2_kernel<BM2, BN, CONV>;
+    auto kfn = gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS>;
     if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
       anip_set_error("anip_gemm: cannot raise the dynamic LDS limit to %d bytes", LDS);
       return -2;
     }
     attr_done = true;
   }
+  static const int dbg = getenv("ANIP_GEMM2_DBG") ? atoi(getenv("ANIP_GEMM2_DBG")) : 0;  // kernel experiments only
   const int nbm = (p.M + BM2 - 1) / BM2, nbn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm2_kernel<BM2, BN, CONV>), dim3((unsigned)(nbm * nbn), (unsigned)p.batch, 1), dim3(NT2), LDS, stream, p);
+  hipLaunchKernelGGL((gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS>), dim3((unsigned)(nbm * nbn), (unsigned)p.batch, 1),
+                     dim3(NT2), LDS, stream, p, dbg);
   return 1;
+}
+
+template <int BM2, int BN, int NW, int WNW, int BKT, int NST>
+int dispatch_gemm2(const anip_gemm_params& p, hipStream_t stream) {
+  if (p.conv) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, true, false>(p, stream);
+  if (p.trans_out) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, true>(p, stream);
+  return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, false>(p, stream);
 }
 
 }  // namespace
@@ -353,24 +499,39 @@ int launch_gemm2(const anip_gemm_params& p, hipStream_t stream) {
 int anip_gemm2_try(const anip_gemm_params& p, hipStream_t stream) {
   if (p.M < 1024) return 0;
   if (p.conv) {
-    if (p.Cin % BK2 != 0) return 0;
+    if (p.Cin % 32 != 0 || p.trans_out) return 0;
   } else {
-    if (p.A2 != nullptr && (p.K1 % BK2) != 0) return 0;
+    if (p.A2 != nullptr && (p.K1 % 32) != 0) return 0;
+  }
+  if (p.trans_out && (p.act == 1 || p.out_f32 || p.rowbias || p.residual)) return 0;
+  // the vector paths of the epilogue assume 16-B aligned bases
+  if ((((uintptr_t)p.out | (uintptr_t)p.bias | (uintptr_t)p.residual) & 15) != 0) return 0;
+  if (p.batch > 1 && (p.strideO & 7) != 0) return 0;
+  const int64_t nb = p.batch > 1 ? p.batch : 1;
+  const int64_t mt256 = (p.M + 255) / 256;
+  static const int force = getenv("ANIP_GEMM2_CFG") ? atoi(getenv("ANIP_GEMM2_CFG")) : 0;  // experiments: 1 = never wide, 2 = wide for any K
+
+  // wide tiles (256 x 320 / 256 x 256, BK = 64): every K-tile inside one conv tap / one A source, N padded < 15 %,
+  // and K long enough that the main loop (not the per-tile prologue / epilogue, where two resident blocks per CU
+  // overlap better) dominates — measured crossover between K = 640 and K = 1280
+  const bool k64 = p.conv ? (p.Cin % 64 == 0) : (p.A2 == nullptr || p.K1 % 64 == 0);
+  if (k64 && force != 1 && (p.K >= 1024 || force == 2)) {
+    const int64_t pad320 = (int64_t)((p.N + 319) / 320) * 320, pad256 = (int64_t)((p.N + 255) / 256) * 256;
+    int wbn = 0;
+    if (p.act == 1) wbn = (pad256 * 100 <= (int64_t)p.N * 115) ? 256 : 0;   // GEGLU pairs tiles: even count per wave
+    else if (pad320 <= pad256 && pad320 * 100 <= (int64_t)p.N * 115) wbn = 320;
+    else if (pad256 * 100 <= (int64_t)p.N * 115) wbn = 256;
+    if (wbn != 0 && mt256 * ((p.N + wbn - 1) / wbn) * nb >= 192)          // >= 3/4 of the CUs busy
+      return wbn == 320 ? dispatch_gemm2<256, 320, 8, 4, 64, 2>(p, stream) : dispatch_gemm2<256, 256, 8, 4, 64, 2>(p, stream);
   }
   int bn = 128;
   if (p.act != 1) {
     const int64_t pad128 = (int64_t)((p.N + 127) / 128) * 128, pad160 = (int64_t)((p.N + 159) / 160) * 160;
     if (pad160 < pad128) bn = 160;
   }
-  const int64_t nb = p.batch > 1 ? p.batch : 1;
-  const int64_t tiles256 = (int64_t)((p.M + 255) / 256) * ((p.N + bn - 1) / bn) * nb;
+  const int64_t tiles256 = mt256 * ((p.N + bn - 1) / bn) * nb;
   if (tiles256 * 2 < 128) return 0;
-  if (p.trans_out && (p.act == 1 || p.out_f32 || p.rowbias || p.residual)) return 0;
   const bool big = tiles256 >= 1024;   // >= 2 full rounds of 2 x 256 resident 256-row blocks
-  if (big) {
-    if (bn == 128) return p.conv ? launch_gemm2<256, 128, true>(p, stream) : launch_gemm2<256, 128, false>(p, stream);
-    return p.conv ? launch_gemm2<256, 160, true>(p, stream) : launch_gemm2<256, 160, false>(p, stream);
-  }
-  if (bn == 128) return p.conv ? launch_gemm2<128, 128, true>(p, stream) : launch_gemm2<128, 128, false>(p, stream);
-  return p.conv ? launch_gemm2<128, 160, true>(p, stream) : launch_gemm2<128, 160, false>(p, stream);
+  if (big) return bn == 128 ? dispatch_gemm2<256, 128, 8, 2, 32, 3>(p, stream) : dispatch_gemm2<256, 160, 8, 2, 32, 3>(p, stream);
+  return bn == 128 ? dispatch_gemm2<128, 128, 4, 2, 32, 3>(p, stream) : dispatch_gemm2<128, 160, 4, 2, 32, 3>(p, stream);
 }

@@ -129,16 +129,17 @@ def pack_conv3x3(w):
 
 
 def pack_geglu(w, b):
-    """FeedForward GEGLU projection [8C, C] (+bias [8C]) -> rows grouped per 64 output columns as
-    [64 x value | 64 x gate] so that one 128-wide GEMM tile holds matching value/gate columns."""
+    """FeedForward GEGLU projection [8C, C] (+bias [8C]) -> rows grouped per 16 output columns as
+    [16 x value | 16 x gate]: the value and gate MFMA tiles of one output column then sit in the same lane of
+    the GEMM epilogue, which applies value * gelu(gate) in registers."""
     n2, k = w.shape
     n = n2 // 2
     assert n % 64 == 0, "GEGLU inner dim must be a multiple of 64"
-    wv, wg = w[:n].reshape(n // 64, 64, k), w[n:].reshape(n // 64, 64, k)
+    wv, wg = w[:n].reshape(n // 16, 16, k), w[n:].reshape(n // 16, 16, k)
     wp = torch.cat([wv, wg], dim=1).reshape(n2, k).contiguous()
     bp = None
     if b is not None:
-        bp = torch.cat([b[:n].reshape(n // 64, 64), b[n:].reshape(n // 64, 64)], dim=1).reshape(n2).contiguous()
+        bp = torch.cat([b[:n].reshape(n // 16, 16), b[n:].reshape(n // 16, 16)], dim=1).reshape(n2).contiguous()
     return wp, bp
 
 

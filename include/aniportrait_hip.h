@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ANIP_ABI_VERSION 4
+#define ANIP_ABI_VERSION 5
 
 int anip_version(void);
 const char* anip_last_error(void);
@@ -72,8 +72,8 @@ typedef struct anip_gemm_params {
                                             time-embedding add (resnet.py:226-230) and the collapsed
                                             length-1 CLIP cross-attention (mutual_self_attention.py:191-205) */
   const void* residual; int64_t ldr;     /* fp16 [M][N] added last, or NULL */
-  int act;                               /* 0 none; 1 GEGLU: W/bias rows packed per 128-row tile as
-                                            [64 x h | 64 x gate], out = h * gelu_erf(gate) */
+  int act;                               /* 0 none; 1 GEGLU: W/bias rows packed per 32 as [16 x h | 16 x gate]
+                                            (N % 128 == 0), out[M][N/2] = h * gelu_erf(gate) */
   int batch; int64_t strideA, strideW, strideO; /* batched GEMM over blockIdx.y (elements) */
   /* implicit 3x3 convolution (conv != 0): A is an NHWC image batch, M = Nimg*Hout*Wout, K = 9*Cin,
    * W = [Cout][3][3][Cin].  upsample=1 fuses nearest-2x (resnet.py:72-74) into the gather. */

@@ -32,9 +32,9 @@ def layernorm(x, gamma, beta, eps=1e-5, pe=None, rows_per_frame=0, frames=0):
 
 
 def _geglu_unpack(y):
-    """columns packed per 128 as [64 value | 64 gate] -> value * gelu(gate)"""
+    """columns packed per 32 as [16 value | 16 gate] -> value * gelu(gate)"""
     M, N = y.shape
-    t = y.reshape(M, N // 128, 2, 64)
+    t = y.reshape(M, N // 32, 2, 16)
     return (t[:, :, 0] * F.gelu(t[:, :, 1])).reshape(M, N // 2)
 
 
