@@ -63,10 +63,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
   constexpr int RB = BKT * 2;                  // LDS row bytes
   constexpr int CPR = RB / 16;                 // 16-B chunks per row
   constexpr int RPI = 1024 / RB;               // rows per LDS-DMA instruction
-  // NST = ring depth.  With NST >= 4 the barrier of iteration kt also covers the landing of tile kt+1 (LAND = 1),
-  // so the first fragments of tile kt+1 are fetched at the end of iteration kt and the MFMAs of the next
-  // iteration start right after its barrier.
-  constexpr int LAND = NST >= 4 ? 1 : 0;
+  // NST = ring depth
   constexpr int KH = BKT / 32;                 // 32-deep MFMA steps per K-tile
   constexpr int WMW = NW / WNW;                // waves along M
   constexpr int WTM = BM2 / WMW, WTN = BN / WNW;  // wave tile
@@ -202,45 +199,84 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
     for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int nk = (p.K + BKT - 1) / BKT;
+  constexpr bool PHASED = (NST == 2 && KH == 2 && NW == 8);
+  if (PHASED) {
+    // Role-alternating schedule for the one-block-per-CU wide tiles.  A K-tile is two 32-deep steps; every step is a
+    // LOAD segment (all ds_reads of the step's fragments, plus the DMA issue of the next K-tile on the first step)
+    // and a COMPUTE segment (FM x NB MFMAs on registers only), each closed by an s_barrier.  Waves 4-7 run one
+    // barrier behind waves 0-3 (they execute one extra barrier up front, waves 0-3 one at the end), so on every SIMD
+    // — waves w and w+4 share one — a wave's COMPUTE segment always coincides with its partner's LOAD segment: the
+    // matrix pipe never waits for LDS or for the barrier.
+    //   barrier numbering: group 0 passes #2s after LOAD(s) and #2s+1 after COMPUTE(s); group 1 passes #2s+1 after
+    //   LOAD(s) and #2s+2 after COMPUTE(s).  K-tile t+1 is issued in LOAD(2t) (its stage was last read in LOAD(2t-1),
+    //   complete before #4t-1) and every wave drains its DMA before #4t+3, after which the first reads of tile t+1 follow.
+    const int grp = wave >> 2;
+    issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    for (int s2 = 0; s2 < 2 * nk; ++s2) {
+      const int t = s2 >> 1, kh = s2 & 1;
+      if (kh == 0 && t + 1 < nk) issue(t + 1, (t + 1) & 1);
+      const char* sa = smem + (t & 1) * STAGE;
+      const char* sb = sa + A_BYTES;
+      const int ko = kh ? koff[KH - 1] : koff[0];
+      f16x8 af[FM], bf[NB];
 #pragma unroll
-  for (int t = 0; t < NST - 1; ++t)
-    if (t < nk) issue(t, t);
-  f16x8 bfn[NB];   // LAND: prefetched B fragments / first A fragment of the next K-tile (k-half 0)
-  f16x8 afn;
-  for (int kt = 0; kt < nk; ++kt) {
-    // this wave's parts of tiles kt .. kt+LAND have landed; later tiles (if any were issued) stay in flight
-    if (NST - 2 - LAND > 0 && kt + LAND + 1 < nk) {
-      if (my_b == NB_I) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2 - LAND) * (NA_I + NB_I)) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2 - LAND) * (NA_I + NB_I - 1)) : "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();  // those tiles are complete for all waves; the stage read at kt-1 is free
-    if (kt + NST - 1 < nk) issue(kt + NST - 1, (kt + NST - 1) % NST);
-    const char* sa = smem + (kt % NST) * STAGE;
-    const char* sb = sa + A_BYTES;
+      for (int j = 0; j < NB; ++j) bf[j] = *(const f16x8*)(sb + b_row_off + j * 16 * RB + ko);
 #pragma unroll
-    for (int kh = 0; kh < KH; ++kh) {
-      f16x8 bf[NB];
-      const bool pre = LAND && kh == 0 && kt > 0;   // fragments fetched at the end of the previous iteration
+      for (int i = 0; i < FM; ++i) af[i] = *(const f16x8*)(sa + a_row_off + i * 16 * RB + ko);
+      if (grp == 1 && kh == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_setprio(1);
+      if (!(dbg & 4))
 #pragma unroll
-      for (int t = 0; t < NB; ++t) bf[t] = pre ? bfn[t] : *(const f16x8*)(sb + b_row_off + t * 16 * RB + koff[kh]);
-#pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        const f16x8 af = (pre && i == 0) ? afn : *(const f16x8*)(sa + a_row_off + i * 16 * RB + koff[kh]);
-        if (!(dbg & 4))      // experiment: no MFMAs
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
           for (int j = 0; j < NB; ++j)
-            acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0)
-                              : __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af, acc[i][j], 0, 0, 0);
-      }
+            acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0)
+                              : __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      if (grp == 0 && kh == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (LAND && kt + 1 < nk) {
-      const char* na = smem + ((kt + 1) % NST) * STAGE;
-      const char* nb_ = na + A_BYTES;
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+  } else {
 #pragma unroll
-      for (int t = 0; t < NB; ++t) bfn[t] = *(const f16x8*)(nb_ + b_row_off + t * 16 * RB + koff[0]);
-      afn = *(const f16x8*)(na + a_row_off + koff[0]);
+    for (int t = 0; t < NST - 1; ++t)
+      if (t < nk) issue(t, t);
+    for (int kt = 0; kt < nk; ++kt) {
+      // this wave's part of tile kt has landed; later tiles (if any were issued) stay in flight
+      if (NST > 2 && kt + 1 < nk) {
+        if (my_b == NB_I) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (NA_I + NB_I)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (NA_I + NB_I - 1)) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();  // tile kt is complete for all waves; the stage read at kt-1 is free
+      if (kt + NST - 1 < nk) issue(kt + NST - 1, (kt + NST - 1) % NST);
+      const char* sa = smem + (kt % NST) * STAGE;
+      const char* sb = sa + A_BYTES;
+#pragma unroll
+      for (int kh = 0; kh < KH; ++kh) {
+        f16x8 bf[NB];
+#pragma unroll
+        for (int t = 0; t < NB; ++t) bf[t] = *(const f16x8*)(sb + b_row_off + t * 16 * RB + koff[kh]);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          const f16x8 af = *(const f16x8*)(sa + a_row_off + i * 16 * RB + koff[kh]);
+          if (!(dbg & 4))      // experiment: no MFMAs
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+              acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0)
+                                : __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af, acc[i][j], 0, 0, 0);
+        }
+      }
     }
   }
 
