@@ -9,7 +9,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libaniportrait_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -32,6 +32,7 @@ class GemmParams(C.Structure):
         ("conv", c_int), ("Nimg", c_int), ("Hin", c_int), ("Win", c_int), ("Cin", c_int),
         ("Hout", c_int), ("Wout", c_int), ("stride", c_int), ("pad", c_int), ("upsample", c_int),
         ("trans_out", c_int),
+        ("workspace", c_void_p), ("workspace_bytes", c_int64),
     ]
 
 
@@ -45,6 +46,7 @@ SIGNATURES = {
                                c_int, c_float, c_int, c_void_p, c_void_p]),
     "anip_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_int64,
                                c_int, c_void_p]),
+    "anip_gemm_workspace_bytes": (c_int64, [C.POINTER(GemmParams)]),
     "anip_gemm": (c_int, [C.POINTER(GemmParams), c_void_p]),
     "anip_conv_small": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                 c_int, c_void_p]),

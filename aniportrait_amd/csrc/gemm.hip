@@ -16,6 +16,8 @@
 #include "common.h"
 
 int anip_gemm2_try(const anip_gemm_params& p, hipStream_t stream);  // gemm2.hip
+int anip_gemm2_try_splitk(const anip_gemm_params& p, hipStream_t stream);
+int64_t anip_gemm2_workspace_bytes(const anip_gemm_params& p);
 
 namespace {
 
@@ -296,6 +298,16 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_small_kernel(const anip_gemm
 
 }  // namespace
 
+extern "C" int64_t anip_gemm_workspace_bytes(const anip_gemm_params* pp) {
+  if (pp == nullptr || pp->M <= 0 || pp->N <= 0 || pp->K <= 0) return 0;
+  anip_gemm_params p = *pp;
+  if (p.batch < 1) p.batch = 1;
+  const int64_t extA = p.conv ? (int64_t)p.Nimg * p.Hin * p.Win * p.Cin : (int64_t)p.M * p.lda;
+  if (!(extA * 2 < 0xFFFF0000ll && (int64_t)p.N * p.ldw * 2 < 0xFFFF0000ll && (!p.A2 || (int64_t)p.M * p.lda2 * 2 < 0xFFFF0000ll)))
+    return 0;
+  return anip_gemm2_workspace_bytes(p);
+}
+
 extern "C" int anip_gemm(const anip_gemm_params* pp, void* stream) {
   anip_gemm_params p = *pp;
   ANIP_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "anip_gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
@@ -337,8 +349,10 @@ extern "C" int anip_gemm(const anip_gemm_params* pp, void* stream) {
     const int64_t extA = p.conv ? (int64_t)p.Nimg * p.Hin * p.Win * p.Cin : (int64_t)p.M * p.lda;
     int used = 0;
     if (extA * 2 < 0xFFFF0000ll && (int64_t)p.N * p.ldw * 2 < 0xFFFF0000ll &&
-        (!p.A2 || (int64_t)p.M * p.lda2 * 2 < 0xFFFF0000ll))
-      used = anip_gemm2_try(p, (hipStream_t)stream);
+        (!p.A2 || (int64_t)p.M * p.lda2 * 2 < 0xFFFF0000ll)) {
+      used = anip_gemm2_try_splitk(p, (hipStream_t)stream);
+      if (used == 0) used = anip_gemm2_try(p, (hipStream_t)stream);
+    }
     if (used < 0) return used;
     if (used == 1) {
     } else if (p.conv)

@@ -58,7 +58,7 @@ __device__ __forceinline__ void row_swap(float& x, float& y) {
 //     bounds the smaller tiles (measured: DMA alone = 0.93 ms of the 1.18 ms 8192^3 GEMM).
 template <int BM2, int BN, int NW, int WNW, int BKT, int NST, bool CONV, bool TRANS>
 __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void gemm2_kernel(const anip_gemm_params p,
-                                                                                           const int dbg) {
+                                                                                           const int dbg, const int splitk) {
   constexpr int NT2 = NW * 64;
   constexpr int RB = BKT * 2;                  // LDS row bytes
   constexpr int CPR = RB / 16;                 // 16-B chunks per row
@@ -198,7 +198,14 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
 #pragma unroll
     for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (p.K + BKT - 1) / BKT;
+  // K-tile range of this block: all of K, or — split-K, blockIdx.y = slice — one of `splitk` contiguous slices whose
+  // fp32 partial tile goes to the workspace (the batch offset of the epilogue) and is reduced by splitk_reduce_kernel
+  int kt_begin = 0, nk = (p.K + BKT - 1) / BKT;
+  if (splitk > 1) {
+    const int per = (nk + splitk - 1) / splitk;
+    kt_begin = (int)blockIdx.y * per;
+    nk = max(0, min(nk - kt_begin, per));
+  }
   constexpr bool PHASED = (NST == 2 && KH == 2 && NW == 8);
   if (PHASED) {
     // Role-alternating schedule for the one-block-per-CU wide tiles.  A K-tile is two 32-deep steps; every step is a
@@ -211,13 +218,13 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
     //   LOAD(s) and #2s+2 after COMPUTE(s).  K-tile t+1 is issued in LOAD(2t) (its stage was last read in LOAD(2t-1),
     //   complete before #4t-1) and every wave drains its DMA before #4t+3, after which the first reads of tile t+1 follow.
     const int grp = wave >> 2;
-    issue(0, 0);
+    if (nk > 0) issue(kt_begin, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();
     for (int s2 = 0; s2 < 2 * nk; ++s2) {
       const int t = s2 >> 1, kh = s2 & 1;
-      if (kh == 0 && t + 1 < nk) issue(t + 1, (t + 1) & 1);
+      if (kh == 0 && t + 1 < nk) issue(kt_begin + t + 1, (t + 1) & 1);
       const char* sa = smem + (t & 1) * STAGE;
       const char* sb = sa + A_BYTES;
       const int ko = kh ? koff[KH - 1] : koff[0];
@@ -249,7 +256,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
   } else {
 #pragma unroll
     for (int t = 0; t < NST - 1; ++t)
-      if (t < nk) issue(t, t);
+      if (t < nk) issue(kt_begin + t, t);
     for (int kt = 0; kt < nk; ++kt) {
       // this wave's part of tile kt has landed; later tiles (if any were issued) stay in flight
       if (NST > 2 && kt + 1 < nk) {
@@ -259,7 +266,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __builtin_amdgcn_s_barrier();  // tile kt is complete for all waves; the stage read at kt-1 is free
-      if (kt + NST - 1 < nk) issue(kt + NST - 1, (kt + NST - 1) % NST);
+      if (kt + NST - 1 < nk) issue(kt_begin + kt + NST - 1, (kt + NST - 1) % NST);
       const char* sa = smem + (kt % NST) * STAGE;
       const char* sb = sa + A_BYTES;
 #pragma unroll
@@ -502,7 +509,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
 }
 
 template <int BM2, int BN, int NW, int WNW, int BKT, int NST, bool CONV, bool TRANS>
-int launch_gemm2(const anip_gemm_params& p, hipStream_t stream) {
+int launch_gemm2(const anip_gemm_params& p, hipStream_t stream, int splitk = 1) {
   constexpr int NT2 = NW * 64;
   constexpr int LDS = NST * (BM2 + BN) * BKT * 2;
   static bool attr_done = false;
@@ -517,18 +524,137 @@ int launch_gemm2(const anip_gemm_params& p, hipStream_t stream) {
   static const int dbg = getenv("ANIP_GEMM2_DBG") ? atoi(getenv("ANIP_GEMM2_DBG")) : 0;  // kernel experiments only
   const int nbm = (p.M + BM2 - 1) / BM2, nbn = (p.N + BN - 1) / BN;
   hipLaunchKernelGGL((gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS>), dim3((unsigned)(nbm * nbn), (unsigned)p.batch, 1),
-                     dim3(NT2), LDS, stream, p, dbg);
+                     dim3(NT2), LDS, stream, p, dbg, splitk);
   return 1;
 }
 
 template <int BM2, int BN, int NW, int WNW, int BKT, int NST>
-int dispatch_gemm2(const anip_gemm_params& p, hipStream_t stream) {
-  if (p.conv) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, true, false>(p, stream);
-  if (p.trans_out) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, true>(p, stream);
-  return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, false>(p, stream);
+int dispatch_gemm2(const anip_gemm_params& p, hipStream_t stream, int splitk = 1) {
+  if (p.conv) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, true, false>(p, stream, splitk);
+  if (p.trans_out) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, true>(p, stream, splitk);
+  return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, false>(p, stream, splitk);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// split-K second pass: out = epilogue(alpha * sum_s ws[s]) with bias / row-group bias / residual, 4 columns per thread
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ ws, int S, const anip_gemm_params p) {
+  const int64_t MN = (int64_t)p.M * p.N;
+  const int64_t nq = MN >> 2;
+  const int nq_row = p.N >> 2;
+  for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nq; q += (int64_t)gridDim.x * 256) {
+    const int m = (int)(q / nq_row), n = (int)(q - (int64_t)m * nq_row) * 4;
+    float4 a = *(const float4*)(ws + q * 4);
+    for (int s_ = 1; s_ < S; ++s_) {
+      const float4 b = *(const float4*)(ws + (int64_t)s_ * MN + q * 4);
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float v[4] = {a.x * p.alpha, a.y * p.alpha, a.z * p.alpha, a.w * p.alpha};
+    if (p.bias != nullptr) {
+      const float4 b = *(const float4*)(p.bias + n);
+      v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if (p.rowbias != nullptr) {
+      const float* rb = p.rowbias + ((int64_t)m / p.rows_per_group) * p.ld_rowbias + n;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += rb[e];
+    }
+    if (p.residual != nullptr) {
+      const f16* rp = (const f16*)p.residual + (int64_t)m * p.ldr + n;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += (float)rp[e];
+    }
+    if (p.out_f32) {
+      float* op = (float*)p.out + (int64_t)m * p.ldo + n;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) op[e] = v[e];
+    } else {
+      f16* op = (f16*)p.out + (int64_t)m * p.ldo + n;
+      if ((p.ldo & 3) == 0 && (((uintptr_t)p.out) & 7) == 0) {
+        union { u32x2 u; f16 e[4]; } t;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t.e[e] = (f16)v[e];
+        *(u32x2*)op = t.u;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) op[e] = (f16)v[e];
+      }
+    }
+  }
 }
 
 }  // namespace
+
+// split factor for problems with too few tiles to fill the chip (1 = no split); *cfg = tile configuration:
+// 128 / 160: 128-row 4-wave tiles of that width; 256 / 320: the wide 256-row tiles of that width
+static int gemm2_split(const anip_gemm_params& p, int* cfg) {
+  if (p.batch > 1 || p.act == 1 || p.trans_out || p.M < 1024 || p.M > 16384 || (p.N & 3) != 0) return 1;
+  if (p.conv ? (p.Cin % 32 != 0) : (p.A2 != nullptr && (p.K1 % 32) != 0)) return 1;
+  if ((((uintptr_t)p.bias | (uintptr_t)p.rowbias) & 15) != 0) return 1;
+  if (p.M > 4096) {
+    // mid-size M (the 16x16 level): 2..4 slices of the wide tiles when those alone leave half the CUs idle
+    const bool k64 = p.conv ? (p.Cin % 64 == 0) : (p.A2 == nullptr || p.K1 % 64 == 0);
+    if (!k64 || p.K < 4096) return 1;
+    const int64_t pad320 = (int64_t)((p.N + 319) / 320) * 320, pad256 = (int64_t)((p.N + 255) / 256) * 256;
+    int wbn = 0;
+    if (pad320 <= pad256 && pad320 * 100 <= (int64_t)p.N * 115) wbn = 320;
+    else if (pad256 * 100 <= (int64_t)p.N * 115) wbn = 256;
+    if (wbn == 0) return 1;
+    const int64_t tiles = (int64_t)((p.M + 255) / 256) * ((p.N + wbn - 1) / wbn);
+    if (tiles >= 192) return 1;
+    const int nk = (p.K + 63) / 64;
+    int S = (int)min((int64_t)4, (256 + tiles - 1) / tiles);
+    S = min(S, nk / 16);                     // slices at least 1024 deep
+    if (S < 2) return 1;
+    *cfg = wbn;
+    const int per = (nk + S - 1) / S;
+    return (nk + per - 1) / per;
+  }
+  const int64_t pad128 = (int64_t)((p.N + 127) / 128) * 128, pad160 = (int64_t)((p.N + 159) / 160) * 160;
+  const int bn = pad160 < pad128 ? 160 : 128;
+  *cfg = bn;
+  const int64_t tiles = (int64_t)((p.M + 127) / 128) * ((p.N + bn - 1) / bn);
+  if (tiles * 2 < 128 || tiles >= 320) return 1;
+  const int nk = (p.K + 31) / 32;
+  int S = (int)min((int64_t)8, (512 + tiles - 1) / tiles);
+  S = min(S, nk / 16);                       // slices at least 512 deep
+  if (S < 2) return 1;
+  const int per = (nk + S - 1) / S;
+  return (nk + per - 1) / per;               // every slice non-empty
+}
+
+int64_t anip_gemm2_workspace_bytes(const anip_gemm_params& p) {
+  int bn;
+  const int S = gemm2_split(p, &bn);
+  return S > 1 ? (int64_t)S * p.M * p.N * 4 : 0;
+}
+
+// split-K path: 1 if launched (partials + reduce), 0 if the problem is not split, < 0 on error
+int anip_gemm2_try_splitk(const anip_gemm_params& p, hipStream_t stream) {
+  int bn = 128;
+  const int S = gemm2_split(p, &bn);
+  if (S <= 1) return 0;
+  const int64_t need = (int64_t)S * p.M * p.N * 4;
+  if (p.workspace == nullptr || p.workspace_bytes < need || (((uintptr_t)p.workspace) & 15) != 0) {
+    anip_set_error("anip_gemm: this problem is split over K and needs %lld bytes of 16-B aligned workspace "
+                   "(anip_gemm_workspace_bytes); got %lld", (long long)need, (long long)p.workspace_bytes);
+    return -1;
+  }
+  anip_gemm_params q = p;
+  q.out = p.workspace; q.ldo = p.N; q.out_f32 = 1;
+  q.alpha = 1.0f; q.bias = nullptr; q.rowbias = nullptr; q.residual = nullptr;
+  q.batch = S; q.strideA = 0; q.strideW = 0; q.strideO = (int64_t)p.M * p.N;
+  int rc;
+  if (bn == 128) rc = dispatch_gemm2<128, 128, 4, 2, 32, 3>(q, stream, S);
+  else if (bn == 160) rc = dispatch_gemm2<128, 160, 4, 2, 32, 3>(q, stream, S);
+  else if (bn == 256) rc = dispatch_gemm2<256, 256, 8, 4, 64, 2>(q, stream, S);
+  else rc = dispatch_gemm2<256, 320, 8, 4, 64, 2>(q, stream, S);
+  if (rc < 0) return rc;
+  const int64_t nq = ((int64_t)p.M * p.N) >> 2;
+  const unsigned blocks = (unsigned)min((int64_t)4096, (nq + 255) / 256);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)p.workspace, S, p);
+  return 1;
+}
 
 // returns 1 if the problem was launched on gemm2, 0 if it is not eligible (caller falls back to the
 // small-problem kernel), < 0 on error

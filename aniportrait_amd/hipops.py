@@ -262,6 +262,11 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
                     f"{' A2' if A2 is not None else ''}{' rb' if rowbias is not None else ''}"
                     f"{' res' if residual is not None else ''}{' T' if trans_out else ''}{' f32' if out_f32 else ''}")
         _work(K_CONV3X3 if conv is not None else K_GEMM, 2 * M * N * K * max(1, int(p.batch)), desc)
+    if M <= 16384:   # few output tiles: the library may want fp32 scratch for split-K
+        wsb = lib.anip_gemm_workspace_bytes(C.byref(p))
+        if wsb > 0:
+            ws = torch.empty((wsb,), dtype=torch.uint8, device=A.device)
+            p.workspace, p.workspace_bytes = _p(ws), wsb
     L.check(lib.anip_gemm(C.byref(p), _stream()), "anip_gemm")
     return out
 

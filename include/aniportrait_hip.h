@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ANIP_ABI_VERSION 5
+#define ANIP_ABI_VERSION 6
 
 int anip_version(void);
 const char* anip_last_error(void);
@@ -80,7 +80,13 @@ typedef struct anip_gemm_params {
   int conv; int Nimg, Hin, Win, Cin, Hout, Wout, stride, pad, upsample;
   int trans_out;                         /* 1: store the result transposed, out[n*ldo + m] (fp16; bias only):
                                             V^T = (x W_v^T)^T for anip_ref_attention */
+  /* split-K for problems with too few output tiles to fill 256 CUs (the 8x8 / 16x16 levels: M = 2048, K up to
+   * 23040): anip_gemm_workspace_bytes(p) > 0 means anip_gemm wants that many bytes of device scratch in
+   * `workspace` (fp32 partial tiles [split][M][N], reduced with the whole epilogue by a second kernel);
+   * 0 means no workspace is needed.  The library never allocates. */
+  void* workspace; int64_t workspace_bytes;
 } anip_gemm_params;
+int64_t anip_gemm_workspace_bytes(const anip_gemm_params* p);
 int anip_gemm(const anip_gemm_params* p, void* stream);
 
 /* ---- small-channel direct convolution (Cin or Cout not MFMA-shaped) -----------------------------

@@ -574,3 +574,33 @@ def test_u8_to_f16():
         src = torch.randint(0, 256, (n,), generator=g, dtype=torch.uint8)
         out = ops.u8_to_f16(src.to(DEV), 2.0, -1.0)
         assert torch.equal(out.cpu(), (src.float() * 2 - 1).half())
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 1280, 5120), (2048, 1280, 1280), (2048, 320, 2560), (4096, 640, 1024), (1100, 1284, 4096),
+                                   (8192, 1280, 5120), (8192, 640, 4096)])
+def test_gemm_split_k(M, N, K):
+    """few output tiles + long K: fp32 partial tiles in the caller's workspace, reduced with the full epilogue"""
+    ops = _ops()
+    A = rnd(M, K, seed=120).to(DEV)
+    W = rnd(N, K, seed=121, scale=K ** -0.5).to(DEV)
+    bias = rnd(N, seed=122).float().to(DEV)
+    rowbias = rnd(4, N, seed=123).float().to(DEV)
+    res = rnd(M, N, seed=124).to(DEV)
+    out = ops.gemm(A, W, bias, rowbias=rowbias, rows_per_group=(M + 3) // 4, residual=res)
+    idx = torch.arange(M) // ((M + 3) // 4)
+    ref = _ref_mm(A, W) + bias.cpu() + rowbias.cpu()[idx] + res.float().cpu()
+    close(out, ref, f"gemm split-K {M}x{N}x{K}")
+    out32 = ops.gemm(A, W, None, out_f32=True, alpha=0.5)
+    close(out32, 0.5 * _ref_mm(A, W), f"gemm split-K f32 {M}x{N}x{K}", rtol=1e-3, arms=1e-3)
+
+
+def test_conv3x3_split_k():
+    ops = _ops()
+    N_, H, Cin, Cout = 32, 8, 1280, 1280
+    x = rnd(N_, H, H, Cin, seed=125).to(DEV)
+    w = rnd(Cout, Cin, 3, 3, seed=126, scale=(9 * Cin) ** -0.5)
+    b = rnd(Cout, seed=127).float()
+    res = rnd(N_, H, H, Cout, seed=128).to(DEV)
+    y = ops.conv3x3(x, ops.pack_conv3x3(w.to(DEV)), b.to(DEV), residual=res)
+    ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.float(), b, padding=1).permute(0, 2, 3, 1) + res.float().cpu()
+    close(y, ref, "conv3x3 split-K 8x8 1280")

@@ -30,3 +30,11 @@ for (M, N, K, geglu, resid) in [(131072, 2560, 320, True, False), (131072, 2560,
 x = r16(32, 64, 64, 320); w = ops.pack_conv3x3(r16(320, 320, 3, 3, scale=(9 * 320) ** -0.5)); b = torch.randn(320, device=DEV)
 res["conv 64^2 320"] = round(timeit(lambda: ops.conv3x3(x, w, b)), 1)
 print(json.dumps({"dbg": dbg, "us": res}))
+res2 = {}
+for (M, N, K) in [(2048, 1280, 5120), (2048, 1280, 1280), (2048, 3840, 1280)]:
+    A, W = r16(M, K), r16(N, K, scale=K ** -0.5); b = torch.randn(N, device=DEV); R = r16(M, N)
+    res2[f"{M}x{N}x{K} res"] = round(timeit(lambda: ops.gemm(A, W, b, residual=R)), 1)
+for (Cin, H) in [(1280, 8), (2560, 8), (1280, 16)]:
+    x = r16(32, H, H, Cin); w = ops.pack_conv3x3(r16(1280, Cin, 3, 3, scale=(9 * Cin) ** -0.5)); b = torch.randn(1280, device=DEV)
+    res2[f"conv {H}^2 {Cin}->1280"] = round(timeit(lambda: ops.conv3x3(x, w, b)), 1)
+print(json.dumps({"dbg": dbg, "small_M_us": res2}))
