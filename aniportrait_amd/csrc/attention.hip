@@ -310,87 +310,111 @@ int launch_ref_attn(const RefAttnArgs& a, int Nf, hipStream_t stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// temporal attention: one wave per (b, pixel, head); F <= 32 frames
-// dynamic LDS per wave: q,k,v [F][d] fp16 + s [F][F] fp32
+// temporal attention (VersatileAttention, src/models/motion_module.py:351-388): for every (b, pixel, head) a
+// softmax attention over the F <= 32 frames.  HBM-bound: 8 B per channel and token.
+// One 256-thread block per (b, pixel, channel group of <= 320 channels = hpg whole heads): the q | k | v segments of
+// the group are contiguous 2*CG-byte pieces of every frame's token row, staged with full-line 16-B loads into
+// LDS [F][CG]; then thread (query frame i, head h) — h fastest, so a wave's lanes read a handful of distinct k / v
+// rows (LDS broadcast) and write neighbouring output segments — computes its 1 x F score row with v_dot2_f32_f16,
+// the softmax in registers and the d outputs 8 channels at a time (fp16 inputs, fp32 accumulation).
 // ---------------------------------------------------------------------------------------------------
+template <int FMAX>
 __global__ __launch_bounds__(NT) void temporal_attn_kernel(const f16* __restrict__ qkv, f16* __restrict__ out, int B,
-                                                          int F, int T, int heads, int d, float scale, int wpb,
-                                                          int64_t nprob) {
+                                                          int F, int T, int heads, int d, float scale_log2e, int hpg,
+                                                          int SL) {
   extern __shared__ __attribute__((aligned(16))) char dsm[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int C = heads * d, dc = d >> 3;
-  const size_t per_wave = ((size_t)3 * F * d * 2 + (size_t)F * F * 4 + 15) & ~(size_t)15;
-  const bool has_wave = wave < wpb;
-  const int64_t prob = (int64_t)blockIdx.x * wpb + wave;
-  const bool valid = has_wave && prob < nprob;
-  char* base = dsm + (size_t)(has_wave ? wave : 0) * per_wave;
-  f16* sq = (f16*)base;
-  f16* sk = sq + F * d;
-  f16* sv = sk + F * d;
-  float* ss = (float*)(sv + F * d);
-  // problem -> (b, t, h), head fastest so neighbouring waves read neighbouring columns
-  const int hh = valid ? (int)(prob % heads) : 0;
-  const int64_t bt = valid ? prob / heads : 0;
-  const int t = (int)(bt % T);
-  const int b = (int)(bt / T);
-
-  if (valid) {
-    for (int c = lane; c < F * dc; c += 64) {
-      const int f = c / dc, ch = c - f * dc;
-      const f16* row = qkv + (((int64_t)b * F + f) * T + t) * (3 * (int64_t)C) + hh * d + ch * 8;
-      *(u32x4*)(sq + f * d + ch * 8) = *(const u32x4*)(row);
-      *(u32x4*)(sk + f * d + ch * 8) = *(const u32x4*)(row + C);
-      *(u32x4*)(sv + f * d + ch * 8) = *(const u32x4*)(row + 2 * C);
+  const int tid = threadIdx.x;
+  const int C = heads * d, CG = hpg * d, ngroups = heads / hpg;
+  const int g = blockIdx.x % ngroups;
+  const int64_t bt = blockIdx.x / ngroups;
+  const int t = (int)(bt % T), b = (int)(bt / T);
+  f16* sq = (f16*)dsm;
+  f16* sk = sq + F * CG;
+  f16* sv = sk + F * CG;
+  const int cpr = CG >> 3;                 // 16-B chunks per (frame, q|k|v) segment
+  const int total = F * 3 * cpr;
+  // all of a thread's loads are issued before the first LDS store (8 per batch): one memory latency per batch,
+  // not one per 16 bytes
+  for (int base = 0; base < total; base += NT * 8) {
+    u32x4 v[8];
+    int dst[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int c = base + u * NT + tid;
+      const bool ok = c < total;
+      const int cc = ok ? c : 0;
+      const int f = cc / (3 * cpr), r = cc - f * (3 * cpr);
+      const int seg = r / cpr, off = r - seg * cpr;
+      dst[u] = ok ? (seg * F + f) * CG + off * 8 : -1;
+      v[u] = *(const u32x4*)(qkv + (((int64_t)b * F + f) * T + t) * (3 * (int64_t)C) + seg * C + g * CG + off * 8);
     }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (dst[u] >= 0) *(u32x4*)(sq + dst[u]) = v[u];
   }
   __syncthreads();
-  if (valid) {
-    for (int e = lane; e < F * F; e += 64) {
-      const int i = e / F, j = e - i * F;
-      float acc = 0.f;
-      for (int ch = 0; ch < dc; ++ch) {
-        U4H8 qa, kb;
-        qa.u = *(const u32x4*)(sq + i * d + ch * 8);
-        kb.u = *(const u32x4*)(sk + j * d + ch * 8);
+  // thread = (item, d-slice): item = (query frame i, head h), h fastest; the head's d/8 chunks are split over SL
+  // adjacent lanes (SL a power of two) whose partial scores are summed with xor-shuffles
+  const int item = tid / SL, sl = tid - item * SL;
+  if (item >= F * hpg) return;
+  const int i = item / hpg, h = item - i * hpg;
+  const int dc = d >> 3;
+  const int c0 = (dc * sl) / SL, c1 = (dc * (sl + 1)) / SL;
+  float s[FMAX];
 #pragma unroll
-        for (int x = 0; x < 8; ++x) acc += (float)qa.e[x] * (float)kb.e[x];
+  for (int j = 0; j < FMAX; ++j) s[j] = 0.f;
+  for (int c = c0; c < c1; ++c) {
+    U4H8 qa;
+    qa.u = *(const u32x4*)(sq + i * CG + h * d + c * 8);
+    const f16x2 q0 = {qa.e[0], qa.e[1]}, q1 = {qa.e[2], qa.e[3]}, q2 = {qa.e[4], qa.e[5]}, q3 = {qa.e[6], qa.e[7]};
+#pragma unroll
+    for (int j = 0; j < FMAX; ++j) {
+      if (j < F) {
+        U4H8 kb;
+        kb.u = *(const u32x4*)(sk + j * CG + h * d + c * 8);
+        float a = s[j];
+        a = __builtin_amdgcn_fdot2(q0, f16x2{kb.e[0], kb.e[1]}, a, false);
+        a = __builtin_amdgcn_fdot2(q1, f16x2{kb.e[2], kb.e[3]}, a, false);
+        a = __builtin_amdgcn_fdot2(q2, f16x2{kb.e[4], kb.e[5]}, a, false);
+        a = __builtin_amdgcn_fdot2(q3, f16x2{kb.e[6], kb.e[7]}, a, false);
+        s[j] = a;
       }
-      ss[e] = acc * scale;
     }
   }
-  __syncthreads();
-  if (valid && lane < F) {
-    float* r = ss + lane * F;
-    float mx = r[0];
-    for (int j = 1; j < F; ++j) mx = fmaxf(mx, r[j]);
-    float sum = 0.f;
-    for (int j = 0; j < F; ++j) {
-      const float p = __expf(r[j] - mx);
-      r[j] = p;
-      sum += p;
-    }
-    const float inv = 1.0f / sum;
-    for (int j = 0; j < F; ++j) r[j] *= inv;
-  }
-  __syncthreads();
-  if (valid) {
-    for (int oidx = lane; oidx < F * dc; oidx += 64) {
-      const int i = oidx / dc, ch = oidx - i * dc;
-      float acc[8];
+  for (int o = 1; o < SL; o <<= 1) {
 #pragma unroll
-      for (int x = 0; x < 8; ++x) acc[x] = 0.f;
-      for (int j = 0; j < F; ++j) {
-        const float p = ss[i * F + j];
+    for (int j = 0; j < FMAX; ++j)
+      if (j < F) s[j] += __shfl_xor(s[j], o, 64);
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < FMAX; ++j)
+    if (j < F) mx = fmaxf(mx, s[j]);
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < FMAX; ++j) {
+    s[j] = (j < F) ? __builtin_amdgcn_exp2f((s[j] - mx) * scale_log2e) : 0.f;
+    sum += s[j];
+  }
+  const float inv = 1.0f / sum;
+  f16* op = out + (((int64_t)b * F + i) * T + t) * (int64_t)C + g * CG + h * d;
+  for (int c = c0; c < c1; ++c) {
+    float acc[8];
+#pragma unroll
+    for (int x = 0; x < 8; ++x) acc[x] = 0.f;
+#pragma unroll
+    for (int j = 0; j < FMAX; ++j) {
+      if (j < F) {
         U4H8 vv;
-        vv.u = *(const u32x4*)(sv + j * d + ch * 8);
+        vv.u = *(const u32x4*)(sv + j * CG + h * d + c * 8);
 #pragma unroll
-        for (int x = 0; x < 8; ++x) acc[x] += p * (float)vv.e[x];
+        for (int x = 0; x < 8; ++x) acc[x] = fmaf((float)vv.e[x], s[j], acc[x]);
       }
-      U4H8 ov;
-#pragma unroll
-      for (int x = 0; x < 8; ++x) ov.e[x] = (f16)acc[x];
-      *(u32x4*)(out + (((int64_t)b * F + i) * T + t) * (int64_t)C + hh * d + ch * 8) = ov.u;
     }
+    U4H8 ov;
+#pragma unroll
+    for (int x = 0; x < 8; ++x) ov.e[x] = (f16)(acc[x] * inv);
+    *(u32x4*)(op + c * 8) = ov.u;
   }
 }
 
@@ -444,16 +468,30 @@ extern "C" int anip_temporal_attention(const void* qkv, void* out, int B, int F,
   ANIP_REQUIRE(qkv && out, "anip_temporal_attention: null pointer");
   ANIP_REQUIRE(B > 0 && T > 0 && heads > 0 && F > 0 && F <= 32, "anip_temporal_attention: need 1 <= F <= 32 (F=%d)", F);
   ANIP_REQUIRE((d & 7) == 0 && d > 0, "anip_temporal_attention: head dim %d must be a multiple of 8", d);
-  const size_t per_wave = ((size_t)3 * F * d * 2 + (size_t)F * F * 4 + 15) & ~(size_t)15;
-  int wpb = 4;
-  while (wpb > 1 && per_wave * wpb > 65536) wpb >>= 1;
-  ANIP_REQUIRE(per_wave * wpb <= 65536, "anip_temporal_attention: LDS budget exceeded (F=%d d=%d)", F, d);
-  const int64_t nprob = (int64_t)B * T * heads;
-  const int64_t blocks = cdiv64(nprob, wpb);
+  ANIP_REQUIRE((((uintptr_t)qkv | (uintptr_t)out) & 15) == 0, "anip_temporal_attention: pointers must be 16-B aligned");
+  // heads per channel group: whole heads, <= 320 channels, one (query frame, head) item per thread
+  int hpg = 1;
+  for (int c = heads; c >= 1; --c)
+    if (heads % c == 0 && c * d <= 320 && c * F <= NT) { hpg = c; break; }
+  ANIP_REQUIRE(hpg * F <= NT, "anip_temporal_attention: F=%d too large", F);
+  const size_t lds = (size_t)3 * F * hpg * d * sizeof(f16);
+  ANIP_REQUIRE(lds <= 65536, "anip_temporal_attention: LDS budget exceeded (F=%d d=%d)", F, d);
+  const int64_t blocks = (int64_t)B * T * (heads / hpg);
+  ANIP_REQUIRE(blocks < (1ll << 31), "anip_temporal_attention: grid too large");
+  const float sl2 = scale * 1.4426950408889634f;
+  int SL = 1;                               // d-slices per item: power of two, <= chunks per head, all 256 threads used
+  while (SL * 2 * hpg * F <= NT && SL * 2 <= (d >> 3)) SL *= 2;
   {
     AnipProfScope prof_(ANIP_K_TEMPORAL_ATTN, (void*)stream);
-    hipLaunchKernelGGL(temporal_attn_kernel, dim3((unsigned)blocks), dim3(NT), per_wave * wpb, (hipStream_t)stream,
-                       (const f16*)qkv, (f16*)out, B, F, T, heads, d, scale, wpb, nprob);
+    if (F <= 8)
+      hipLaunchKernelGGL(temporal_attn_kernel<8>, dim3((unsigned)blocks), dim3(NT), lds, (hipStream_t)stream, (const f16*)qkv,
+                         (f16*)out, B, F, T, heads, d, sl2, hpg, SL);
+    else if (F <= 16)
+      hipLaunchKernelGGL(temporal_attn_kernel<16>, dim3((unsigned)blocks), dim3(NT), lds, (hipStream_t)stream, (const f16*)qkv,
+                         (f16*)out, B, F, T, heads, d, sl2, hpg, SL);
+    else
+      hipLaunchKernelGGL(temporal_attn_kernel<32>, dim3((unsigned)blocks), dim3(NT), lds, (hipStream_t)stream, (const f16*)qkv,
+                         (f16*)out, B, F, T, heads, d, sl2, hpg, SL);
   }
   ANIP_LAUNCH_CHECK("anip_temporal_attention");
   return 0;

@@ -266,7 +266,7 @@ __global__ __launch_bounds__(NT) void softmax_rows_kernel(const float* __restric
 
 static void gn_chunks(int N, int64_t HW, int* nchunks, int64_t* ppc) {
   int64_t want = (1024 + N - 1) / N;          // aim at >= ~1024 workgroups
-  int64_t maxc = (HW + 63) / 64;              // at least 64 pixels per chunk
+  int64_t maxc = (HW + 15) / 16;              // at least 16 pixels per chunk (small maps still get >= 128 workgroups)
   int64_t nc = want < maxc ? want : maxc;
   if (nc < 1) nc = 1;
   if (nc > 256) nc = 256;
