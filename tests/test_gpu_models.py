@@ -110,11 +110,12 @@ def test_vae_matches_reference(setup):
     enc = m["vae"].encode(v["x"].to(DEV)).latent_dist.mean
     assert rel_err(dec.cpu(), gold["vae_dec"]) < TOL
     assert rel_err(enc.cpu(), gold["vae_enc"]) < TOL
-    # frames are independent: a batch of different latents decodes to the same frames as one by one
+    # frames are independent: a batch of different latents decodes to the same frames as one by one (up to fp32
+    # summation order: the GEMM tile / split-K configuration is chosen from the problem size, i.e. the batch)
     z = torch.cat([v["z"], v["z"].flip(-1), -v["z"]]).to(DEV)
     both = m["vae"].decode(z).sample
     for i in range(3):
-        assert torch.equal(both[i:i + 1], m["vae"].decode(z[i:i + 1]).sample)
+        assert rel_err(both[i:i + 1].cpu(), m["vae"].decode(z[i:i + 1]).sample.cpu()) < 2e-3
 
 
 @torch.no_grad()
