@@ -172,6 +172,8 @@ def main():
         torch.cuda.set_device(0)
     n_gpus = world
     assert a.gpus == n_gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if world > 1:  # the per-clip host work (PIL resize, CLIP preprocessing) is tiny: do not oversubscribe the host cores
+        torch.set_num_threads(max(1, (os.cpu_count() or 8) // (2 * world)))
     device = torch.device("cuda", local_rank if world > 1 else 0)
 
     H = W = a.size
