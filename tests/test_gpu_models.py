@@ -217,3 +217,49 @@ def test_full_size_properties_512():
     assert torch.equal(a[0], b[0])            # unconditional half: independent of the bank
     assert not torch.equal(a[1], b[1])        # conditional half: attends to it
     rd.clear()
+
+
+@torch.no_grad()
+def test_full_size_properties_768():
+    """BASELINE configs[4] geometry (768x768 -> 96x96 latents, T = 9216 tokens per frame), real widths, 2 frames per CFG
+    half: the kernels' tile / grid / 32-bit-offset logic at the largest size of the path.  Properties instead of an
+    oracle (far too slow on the CPU): finite output of the right shape, CFG-unconditional frames independent of the
+    bank, temporal attention really mixing frames (changing frame 1 changes frame 0's output), VAE decode of one
+    96x96 latent in range."""
+    from aniportrait_amd import configs as C
+    from aniportrait_amd.autoencoder_kl import AutoencoderKL
+    from aniportrait_amd.params import skip_init
+    from aniportrait_amd.pipeline_pose2vid_long import bank_shapes
+    from aniportrait_amd.synthetic import fast_fill_
+    from aniportrait_amd.unet import UNet3DConditionModel
+    from src.models.mutual_self_attention import ReferenceAttentionControl
+    with skip_init():
+        net = UNet3DConditionModel(**C.unet3d_kwargs(False))
+        vae = AutoencoderKL(**C.SD_VAE_FT_MSE)
+    net = fast_fill_(net.to(DEV, torch.float16), 5)
+    vae = fast_fill_(vae.to(DEV, torch.float16), 6)
+    rd = ReferenceAttentionControl(net, do_classifier_free_guidance=True, mode="read", fusion_blocks="full")
+    f, h = 2, 96
+    shapes = bank_shapes(net.config, 2, h, h)
+
+    def set_banks(seed):
+        gg = torch.Generator(device=DEV).manual_seed(seed)
+        for p, rb in net._ref_blocks.items():
+            rb.node.bank = [torch.randn(shapes[p], generator=gg, device=DEV).half()]
+
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x = torch.randn((1, 4, f, h, h), generator=g, device=DEV).half().repeat(2, 1, 1, 1, 1)
+    ehs = torch.cat([torch.zeros(1, 1, 768, device=DEV), torch.randn((1, 1, 768), generator=g, device=DEV)]).half()
+    set_banks(1)
+    a = net(x, 519, ehs, return_dict=False)[0]
+    set_banks(2)
+    b = net(x, 519, ehs, return_dict=False)[0]
+    assert a.shape == (2, 4, f, h, h) and torch.isfinite(a).all()
+    assert torch.equal(a[0], b[0]) and not torch.equal(a[1], b[1])
+    x2 = x.clone()
+    x2[:, :, 1] += 0.5
+    c = net(x2, 519, ehs, return_dict=False)[0]
+    assert not torch.equal(c[0, :, 0], b[0, :, 0])
+    rd.clear()
+    img = vae.decode(torch.randn((1, 4, h, h), generator=g, device=DEV).half()).sample
+    assert img.shape == (1, 3, 8 * h, 8 * h) and torch.isfinite(img).all()
