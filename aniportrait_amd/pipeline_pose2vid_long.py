@@ -401,7 +401,9 @@ class Pose2VideoPipeline:
         temb_table = torch.stack([engine.timestep_sinusoid(t, S, ucfg["block_out_channels"][0], "cpu",
                                                            ucfg.get("flip_sin_to_cos", True), ucfg.get("freq_shift", 0))
                                   for t in timesteps]).to(device)
-        use_graph = bool(use_graph) and device.type == "cuda" and ops._WORK is None
+        # (ANIP_NO_GRAPH=1: eager launches, for profilers whose counter collection cannot follow graph replays)
+        use_graph = (bool(use_graph) and device.type == "cuda" and ops._WORK is None and
+                     not os.environ.get("ANIP_NO_GRAPH"))
         runners = self._get_runners()
         clip_runners = {}
 
