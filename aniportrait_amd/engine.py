@@ -9,7 +9,7 @@ src/models/transformer_3d.py:128-153 do not exist here and every 1x1 conv is a p
 
 `PackedNet` turns a reference-format state-dict into kernel-ready device tensors once:
 3x3 conv weights [Cout][ky][kx][Cin], fused [to_q;to_k] / [to_q;to_k;to_v] projection matrices,
-GEGLU rows interleaved per 64 columns, all time_emb_proj layers stacked into one matrix, fp32 norm
+GEGLU rows interleaved per 16 output columns, all time_emb_proj layers stacked into one matrix, fp32 norm
 parameters and biases.
 
 Legal shortcuts relative to the reference's op sequence (identical results):
