@@ -85,3 +85,66 @@ def test_sharding_helpers_single_process():
     assert D.allreduce_window_sums(a, c)[0] is a
     out = D.gather_frames(torch.arange(6.0).reshape(3, 2), [2, 0, 1], 3)
     assert out.tolist() == [[2.0, 3.0], [4.0, 5.0], [0.0, 1.0]]
+
+
+class _Patch:
+    """minimal stand-in for pytest's monkeypatch inside a spawned worker"""
+
+    def setattr(self, obj, name, value):
+        setattr(obj, name, value)
+
+
+def _pipeline_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [here, os.path.dirname(here)]
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import emu_hipops
+        emu_hipops.install(_Patch())
+        from aniportrait_amd import configs as C
+        from aniportrait_amd.scheduling_ddim import DDIMScheduler
+        from golden_inputs import pipe_inputs
+        from src.pipelines.pipeline_pose2vid_long import Pose2VideoPipeline
+        from util import build_hip_models, load_golden, psnr, small_clip_encoder
+        m, _ = build_hip_models(True, device="cpu")
+        i = pipe_inputs("long_L10_ctx8")       # L = 10, 8-frame windows: two windows per step -> one per rank
+        pipe = Pose2VideoPipeline(vae=m["vae"], image_encoder=small_clip_encoder("cpu"), reference_unet=m["reference_unet"],
+                                  denoising_unet=m["denoising_unet"], pose_guider=m["pose_guider"],
+                                  scheduler=DDIMScheduler(**C.DDIM_V2))
+        pipe.set_progress_bar_config(disable=True)
+        if rank != 0:  # only rank 0's ReferenceNet banks may be used: break the others' ReferenceNet
+            for p_ in m["reference_unet"].parameters():
+                p_.data.zero_()
+            m["reference_unet"]._invalidate()
+        out = pipe(i["ref_image"], list(i["poses"]), i["ref_pose"], i["W"], i["H"], i["L"], i["steps"], i["cfg"],
+                   latents=i["latents"], dp_group=dist.group.WORLD, **i["kw"])
+        if rank == 0:
+            gold = load_golden("small_pipeline.pt")
+            q.put((rank, float(psnr(out.videos, gold["long_L10_ctx8/video_f16"].float())), tuple(out.videos.shape)))
+        else:
+            q.put((rank, out is None, None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_long_clip_pipeline_matches_reference():
+    """One long clip on 2 ranks (gloo, CPU, kernel wrappers emulated — tests/emu_hipops.py): windows sharded round
+    robin, rank 0's ReferenceNet banks broadcast, per-step all-reduce of the window sums, frames decoded per rank
+    and gathered — the decoded video on rank 0 matches the reference's single-process pipeline."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert res[0][0] == 0 and res[0][1] >= 40.0 and res[0][2] == (1, 3, 10, 128, 128), res
+    assert res[1][0] == 1 and res[1][1] is True, res
