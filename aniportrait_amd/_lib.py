@@ -9,7 +9,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libaniportrait_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -48,6 +48,8 @@ SIGNATURES = {
                                c_int, c_void_p]),
     "anip_gemm_workspace_bytes": (c_int64, [C.POINTER(GemmParams)]),
     "anip_gemm": (c_int, [C.POINTER(GemmParams), c_void_p]),
+    "anip_ffn_geglu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
+                               c_void_p]),
     "anip_conv_small": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                 c_int, c_void_p]),
     "anip_conv_direct": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

@@ -22,6 +22,7 @@ Legal shortcuts relative to the reference's op sequence (identical results, SURV
     neighbouring GroupNorm / conv / GEMM kernels.
 """
 import math
+import os
 
 import torch
 
@@ -171,9 +172,14 @@ def resnet(net, p, x, skip, temb_rb, rows_per_group, eps, groups=32):
                        residual=sc)
 
 
+_FUSED_FFN = bool(os.environ.get("ANIP_FUSED_FFN"))   # experimental single-kernel feed-forward (csrc/ffn.hip), off by default
+
+
 def feed_forward(net, p, n_in, residual):
     """diffusers FeedForward(geglu) + residual: GEGLU fused in the first GEMM's epilogue."""
     wp, bp = net.geglu(p + ".net.0.proj")
+    if _FUSED_FFN and n_in.shape[1] == 320 and net.has(p + ".net.2.bias"):
+        return ops.ffn_geglu(n_in, wp, bp, net.lin(p + ".net.2.weight"), net.f32(p + ".net.2.bias"), residual)
     g = ops.gemm(n_in, wp, bp, act=1)
     return ops.gemm(g, net.lin(p + ".net.2.weight"), net.f32(p + ".net.2.bias"), residual=residual)
 

@@ -271,6 +271,22 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
     return out
 
 
+def ffn_geglu(x, w1p, b1p, w2, b2, residual=None):
+    """EXPERIMENTAL fused GEGLU feed-forward (anip_ffn_geglu; C = 320 only): x (M, C) fp16, w1p / b1p packed by
+    pack_geglu, w2 (C, 4C) fp16, b2 (C,) fp32, residual (M, C) fp16 -> (M, C) fp16."""
+    lib = L.load()
+    _req(x, F16, "x")
+    _req(w1p, F16, "w1p")
+    _req(w2, F16, "w2")
+    M, Cc = x.shape
+    assert tuple(w1p.shape) == (8 * Cc, Cc) and tuple(w2.shape) == (Cc, 4 * Cc)
+    out = torch.empty_like(x)
+    _work(K_GEMM, 2 * M * Cc * (8 * Cc) + 2 * M * Cc * (4 * Cc), f"ffn_geglu M{M} C{Cc}")
+    L.check(lib.anip_ffn_geglu(_p(x), _p(w1p), _p(_req(b1p, F32, "b1p")), _p(w2), _p(b2), _p(residual), _p(out), M, Cc,
+                               _stream()), "anip_ffn_geglu")
+    return out
+
+
 def conv3x3(x, Wp, bias, stride=1, pad=1, upsample=False, pad_hi=None, rowbias=None, rows_per_group=0,
             residual=None, out_f32=False):
     """x (N, H, W, Cin) fp16, Wp (Cout, 9*Cin) packed by pack_conv3x3 -> (N, Ho, Wo, Cout).

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ANIP_ABI_VERSION 6
+#define ANIP_ABI_VERSION 7
 
 int anip_version(void);
 const char* anip_last_error(void);
@@ -88,6 +88,15 @@ typedef struct anip_gemm_params {
 } anip_gemm_params;
 int64_t anip_gemm_workspace_bytes(const anip_gemm_params* p);
 int anip_gemm(const anip_gemm_params* p, void* stream);
+
+/* ---- fused GEGLU feed-forward (EXPERIMENTAL, see csrc/ffn.hip; the engine uses it only with ANIP_FUSED_FFN=1) -----
+ * out[M][C] = residual + b2 + W2 · ((x W1v^T + b1v) * gelu_erf(x W1g^T + b1g)):  diffusers FeedForward("geglu") of
+ * src/models/attention.py:361 / src/models/motion_module.py:233 plus the block's residual add, without the M x 4C
+ * intermediate ever leaving the CU.  x [M][C] fp16; w1p [8C][C] fp16 and b1p [8C] fp32 packed per 32 rows as
+ * [16 value | 16 gate] (the GEGLU packing of anip_gemm); w2 [C][4C] fp16; b2 [C] fp32 or NULL; residual [M][C]
+ * fp16 or NULL.  Only C = 320 is built. */
+int anip_ffn_geglu(const void* x, const void* w1p, const float* b1p, const void* w2, const float* b2,
+                   const void* residual, void* out, int64_t M, int C, void* stream);
 
 /* ---- small-channel direct convolution (Cin or Cout not MFMA-shaped) -----------------------------
  * conv_in 4->C (src/models/unet_3d.py:90-92,484), AutoencoderKL post_quant_conv / decoder.conv_in.

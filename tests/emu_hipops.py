@@ -84,6 +84,16 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
     return y
 
 
+def ffn_geglu(x, w1p, b1p, w2, b2, residual=None):
+    h = _geglu_unpack(x.float() @ w1p.float().t() + b1p.float()).to(F16)     # the kernel rounds H to fp16 too
+    y = h.float() @ w2.float().t()
+    if b2 is not None:
+        y = y + b2.float()
+    if residual is not None:
+        y = y + residual.float()
+    return y.to(F16)
+
+
 def conv3x3(x, Wp, bias, stride=1, pad=1, upsample=False, pad_hi=None, rowbias=None, rows_per_group=0,
             residual=None, out_f32=False):
     N, H, Wd, Cin = x.shape
@@ -216,7 +226,7 @@ def u8_to_f16(src, scale=1.0, shift=0.0):
     return (src.float() * scale + shift).to(F16)
 
 
-_EMULATED = ("groupnorm", "layernorm", "gemm", "conv3x3", "conv_small", "conv_direct", "batchnorm", "ref_attention",
+_EMULATED = ("groupnorm", "layernorm", "gemm", "ffn_geglu", "conv3x3", "conv_small", "conv_direct", "batchnorm", "ref_attention",
              "temporal_attention", "softmax_rows", "linear_small", "add", "window_accumulate", "cfg_ddim_step",
              "ncfhw_to_nhwc", "nhwc_to_ncfhw", "u8_to_f16")
 

@@ -604,3 +604,23 @@ def test_conv3x3_split_k():
     y = ops.conv3x3(x, ops.pack_conv3x3(w.to(DEV)), b.to(DEV), residual=res)
     ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.float(), b, padding=1).permute(0, 2, 3, 1) + res.float().cpu()
     close(y, ref, "conv3x3 split-K 8x8 1280")
+
+
+@pytest.mark.skipif(not __import__("os").environ.get("ANIP_FUSED_FFN"),
+                    reason="experimental fused feed-forward (csrc/ffn.hip): enabled and checked with ANIP_FUSED_FFN=1")
+@pytest.mark.parametrize("M", [128, 4096, 5000])
+def test_ffn_geglu_fused(M):
+    ops = _ops()
+    Cc = 320
+    x = rnd(M, Cc, seed=130).to(DEV)
+    W1 = rnd(8 * Cc, Cc, seed=131, scale=Cc ** -0.5)
+    b1 = rnd(8 * Cc, seed=132).float()
+    W2 = rnd(Cc, 4 * Cc, seed=133, scale=(4 * Cc) ** -0.5)
+    b2 = rnd(Cc, seed=134).float()
+    res = rnd(M, Cc, seed=135)
+    w1p, b1p = ops.pack_geglu(W1, b1)
+    out = ops.ffn_geglu(x, w1p.to(DEV), b1p.to(DEV), W2.to(DEV), b2.to(DEV), res.to(DEV))
+    hv, hg = (_ref_mm(x, W1) + b1).chunk(2, dim=-1)
+    h = (hv * F.gelu(hg)).half()
+    ref = _ref_mm(h, W2) + b2 + res.float()
+    close(out, ref, f"ffn_geglu fused M={M}", rtol=3e-3, arms=3e-3)
