@@ -606,8 +606,6 @@ def test_conv3x3_split_k():
     close(y, ref, "conv3x3 split-K 8x8 1280")
 
 
-@pytest.mark.skipif(not __import__("os").environ.get("ANIP_FUSED_FFN"),
-                    reason="experimental fused feed-forward (csrc/ffn.hip): enabled and checked with ANIP_FUSED_FFN=1")
 @pytest.mark.parametrize("M", [128, 4096, 5000])
 def test_ffn_geglu_fused(M):
     ops = _ops()
@@ -624,3 +622,6 @@ def test_ffn_geglu_fused(M):
     h = (hv * F.gelu(hg)).half()
     ref = _ref_mm(h, W2) + b2 + res.float()
     close(out, ref, f"ffn_geglu fused M={M}", rtol=3e-3, arms=3e-3)
+    # same rounding points and accumulation order as the two-GEMM path: bit-identical
+    two = ops.gemm(ops.gemm(x, w1p.to(DEV), b1p.to(DEV), act=1), W2.to(DEV), b2.to(DEV), residual=res.to(DEV))
+    assert torch.equal(out, two)
