@@ -2,8 +2,8 @@
 // — diffusers FeedForward(activation_fn="geglu") as used by every (Temporal)BasicTransformerBlock and motion module
 // (src/models/attention.py:361, src/models/motion_module.py:233) plus the block's residual add.
 //
-// Status (round 1): parity-green on MI355X (tests/test_hip_ops.py::test_ffn_geglu_fused: bit-identical to the two-GEMM
-// path at M = 128 / 4096 / 5000) and 435 us vs 644 us for the two launches in isolation at M = 131072 (tools/exp_ffn.py),
+// Status (round 1): parity-green on MI355X (tests/test_hip_ops.py::test_ffn_geglu_fused at M = 128 / 4096 / 5000; bit-identical to
+// the two-GEMM path at M = 131072) and 435 us vs 644 us for the two launches in isolation (tools/exp_ffn.py),
 // but the single end-to-end bench run that still fit in the round's GPU budget was slower with it (1.70 vs 1.62 s per
 // clip), so the engine only uses it with ANIP_FUSED_FFN=1.  Known weakness: every 64-deep K-tile iteration drains the
 // DMA queue (vmcnt(0) + barrier) with only 16 MFMAs per wave to cover it.
