@@ -117,7 +117,9 @@ __global__ __launch_bounds__(NT) void add_kernel(const f16* __restrict__ a, cons
   }
 }
 
-// acc[s][frames[j]][e] += pred[s][j][e]; counter[frames[j]] += 1 (one thread block column for counters)
+// acc[s][frames[j]][e] += pred[s][j][e]; counter[frames[j]] += 1 (one thread block column for counters).
+// frames[j] < 0: window slot j is skipped (the host masks all but the last occurrence of a frame a dilated window
+// visits twice, so no two threads ever update the same element)
 __global__ __launch_bounds__(NT) void window_accumulate_kernel(const f16* __restrict__ pred, float* __restrict__ acc,
                                                               float* __restrict__ counter,
                                                               const int* __restrict__ frames, int S, int Fw, int L,
@@ -130,9 +132,9 @@ __global__ __launch_bounds__(NT) void window_accumulate_kernel(const f16* __rest
     const int j = (int)(sj % Fw);
     const int s = (int)(sj / Fw);
     const int f = frames[j];
-    acc[((int64_t)s * L + f) * HWC + e] += (float)pred[i];
+    if (f >= 0) acc[((int64_t)s * L + f) * HWC + e] += (float)pred[i];
   }
-  if (blockIdx.x == 0 && threadIdx.x < Fw) counter[frames[threadIdx.x]] += 1.0f;
+  if (blockIdx.x == 0 && threadIdx.x < Fw && frames[threadIdx.x] >= 0) counter[frames[threadIdx.x]] += 1.0f;
 }
 
 __global__ __launch_bounds__(NT) void cfg_ddim_kernel(const float* __restrict__ acc, const float* __restrict__ counter,

@@ -190,16 +190,31 @@ def feed_forward(net, p, n_in, residual):
 class RefState:
     """Reference-attention state of one spatial transformer block (what `module.bank` plus the hacked
     forward's closure hold in src/models/mutual_self_attention.py:93-265)."""
-    __slots__ = ("mode", "bank", "kref", "vtref", "stale", "written")
+    __slots__ = ("mode", "bank", "kref", "vtref", "stale", "written", "pool")
 
     def __init__(self):
         self.mode = "plain"   # "plain" | "write" | "read"
         self.bank = None      # (b, T, C) fp16 on device (read mode)
         self.kref = None      # (b*T, C) fp16: to_k(bank)
         self.vtref = None     # (C, b*T) fp16: to_v(bank)^T
-        self.stale = True     # bank replaced since kref / vtref were projected: re-project IN PLACE (the buffers
-                              # keep their addresses, which captured hipGraphs of the forward have baked in)
+        self.stale = True     # bank replaced since kref / vtref were projected: re-project IN PLACE
         self.written = None   # (b, T, C) fp16 produced in write mode
+        # {(rows, C, device): (kref, vtref)} — one projection buffer pair per bank shape, allocated once and never
+        # freed or re-allocated while the packed weights live: captured hipGraphs of the forward have these addresses
+        # baked in, so a clip at another resolution (or a direct forward() call) in between must not recycle them
+        self.pool = {}
+
+    def buffers(self, rows, C, device):
+        key = (int(rows), int(C), str(device))
+        if key not in self.pool:
+            self.pool[key] = (torch.empty((rows, C), dtype=F16, device=device),
+                              torch.empty((C, rows), dtype=F16, device=device))
+        return self.pool[key]
+
+    def drop(self):
+        self.bank = self.kref = self.vtref = None
+        self.stale = True
+        self.pool = {}
 
 
 def transformer_block(net, p, h, Nf, T, heads, attn2_vec, rows_per_sample, ref=None, ref_index=None, stop_after_bank=False):
@@ -221,11 +236,9 @@ def transformer_block(net, p, h, Nf, T, heads, attn2_vec, rows_per_sample, ref=N
             bank2 = ref.bank.reshape(-1, C)
             if bank2.dtype != F16 or bank2.device != net.device:
                 bank2 = bank2.to(net.device, F16)
-            reuse = (ref.kref is not None and tuple(ref.kref.shape) == (bank2.shape[0], C) and
-                     ref.kref.device == bank2.device)
-            ref.kref = ops.gemm(bank2, net.lin(p + ".attn1.to_k.weight"), out=ref.kref if reuse else None)
-            ref.vtref = ops.gemm(bank2, net.lin(p + ".attn1.to_v.weight"), trans_out=True,
-                                 out=ref.vtref if reuse else None)
+            kbuf, vbuf = ref.buffers(bank2.shape[0], C, net.device)
+            ref.kref = ops.gemm(bank2, net.lin(p + ".attn1.to_k.weight"), out=kbuf)
+            ref.vtref = ops.gemm(bank2, net.lin(p + ".attn1.to_v.weight"), trans_out=True, out=vbuf)
             ref.stale = False
         assert ref.bank.shape[1] == T, "reference bank token count differs from the denoising latents"
         kw = dict(kref=ref.kref, ldkr=C, vtref=ref.vtref, ldvtr=ref.vtref.shape[1], ref_index=ref_index[0],
@@ -324,32 +337,39 @@ def attention_paths(cfg):
 
 
 class Attn2Cache:
-    """to_out(to_v(e)) of every spatial transformer block for the current CLIP embedding: constant over
-    DDIM steps, recomputed only when the embedding tensor changes."""
+    """to_out(to_v(e)) of every spatial transformer block for a CLIP embedding e: constant over DDIM steps.
+
+    The vectors live in one buffer set per embedding shape, allocated once and rewritten IN PLACE (captured hipGraphs
+    of the forward read them).  There is no content cache: `get(..., refresh=True)` — the default of every forward —
+    recomputes them from the tensor it is given (32 tiny launches); the pipeline's graph runner passes refresh=False
+    for the steps after the clip's first one, whose eager forward has just written them.  (A pointer / version key,
+    as in round 1, does not identify a tensor's content once the allocator recycles the block.)"""
 
     def __init__(self):
-        self.key = None
-        self.vecs = None
+        self.pool = {}   # (b, device) -> {path: fp32 (b, C)}
 
-    def get(self, net, cfg, ehs):
-        key = (ehs.data_ptr(), ehs._version, tuple(ehs.shape), ehs.dtype)
-        if key != self.key:
-            e = ehs.detach().reshape(ehs.shape[0], -1).to(net.device, F32).contiguous()  # (b, D): sequence length 1
-            vecs, old = {}, self.vecs or {}
-            for p in attention_paths(cfg):
-                a = p + ".transformer_blocks.0.attn2"
-                v = ops.linear_small(e, net.lin(a + ".to_v.weight"))
-                Wo = net.lin(a + ".to_out.0.weight")
-                o = old.get(p)   # rewritten in place: captured hipGraphs keep reading the same buffers
-                if o is not None and (tuple(o.shape) != (e.shape[0], Wo.shape[0]) or o.device != e.device):
-                    o = None
-                vecs[p] = ops.linear_small(v, Wo, net.f32(a + ".to_out.0.bias"), out=o)
-            self.key, self.vecs = key, vecs
-        return self.vecs
+    def drop(self):
+        self.pool = {}
+
+    def get(self, net, cfg, ehs, refresh=True):
+        key = (int(ehs.shape[0]), str(net.device))
+        vecs = self.pool.get(key)
+        if vecs is not None and not refresh:
+            return vecs
+        e = ehs.detach().reshape(ehs.shape[0], -1).to(net.device, F32).contiguous()  # (b, D): sequence length 1
+        old = vecs or {}
+        vecs = {}
+        for p in attention_paths(cfg):
+            a = p + ".transformer_blocks.0.attn2"
+            v = ops.linear_small(e, net.lin(a + ".to_v.weight"))
+            vecs[p] = ops.linear_small(v, net.lin(a + ".to_out.0.weight"), net.f32(a + ".to_out.0.bias"),
+                                       out=old.get(p))
+        self.pool[key] = vecs
+        return vecs
 
 
 def unet_forward(net, cfg, x, b, f, t, ehs, attn2_cache, refs, with_motion, ref_index=None, pose_nhwc=None,
-                 final=True, stop_after_last_bank=False, temb_in=None):
+                 final=True, stop_after_last_bank=False, temb_in=None, attn2_refresh=True):
     """UNet3DConditionModel.forward (src/models/unet_3d.py:399-580) / the ReferenceNet
     UNet2DConditionModel.forward (src/models/unet_2d_condition.py:872-1308, f = 1, no motion modules).
 
@@ -379,7 +399,7 @@ def unet_forward(net, cfg, x, b, f, t, ehs, attn2_cache, refs, with_motion, ref_
     Wt, bt, toffs = net.temb_stack([n + ".time_emb_proj" for n in resnet_names(cfg)])
     temb_all = ops.linear_small(emb, Wt, bt, silu_in=True)  # (b, sum Cout) fp32
 
-    a2 = attn2_cache.get(net, cfg, ehs)
+    a2 = attn2_cache.get(net, cfg, ehs, attn2_refresh)
     last_path = attention_paths(cfg)[-1]
 
     def res(p, x, skip=None):

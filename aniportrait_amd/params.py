@@ -280,6 +280,11 @@ def _default_init(name, shape):
     if _SKIP_INIT:
         return torch.empty(shape)
     leaf = name.rsplit(".", 1)[-1]
+    # layers the reference zero-initialises (src/models/motion_module.py:72-75 `zero_module(proj_out)`,
+    # src/models/pose_guider.py:120-122 `final_proj`): observable through `from_pretrained_2d(mm_zero_proj_out=True)`,
+    # which leaves them at their constructor values
+    if ".temporal_transformer.proj_out." in name or name.startswith("final_proj."):
+        return torch.zeros(shape)
     if len(shape) >= 2:
         fan_in = 1
         for s in shape[1:]:

@@ -19,6 +19,7 @@ import inspect
 import math
 import os
 import time
+from collections import OrderedDict
 
 import numpy as np
 import torch
@@ -91,9 +92,12 @@ class _DenoiseRunner:
             self.x[s_ * self.f:(s_ + 1) * self.f].copy_(x)
 
     def eager(self, x, temb):
+        """the clip's first forward: re-projects the reference banks and recomputes the collapsed-attn2 vectors from
+        this runner's CLIP token, both in place (buffers owned per shape by the UNet, never re-allocated)"""
         self._fill_x(x)
         self.temb.copy_(temb)
-        return self.unet.forward_nhwc(self.x, self.S, self.f, None, self.ehs, self.pose, temb_in=self.temb)
+        return self.unet.forward_nhwc(self.x, self.S, self.f, None, self.ehs, self.pose, temb_in=self.temb,
+                                      attn2_refresh=True)
 
     def replay(self, x, temb):
         self._fill_x(x)
@@ -102,7 +106,7 @@ class _DenoiseRunner:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self.pred = self.unet.forward_nhwc(self.x, self.S, self.f, None, self.ehs, self.pose,
-                                                   temb_in=self.temb)
+                                                   temb_in=self.temb, attn2_refresh=False)
             self.graph = g
         self.graph.replay()
         return self.pred
@@ -134,35 +138,20 @@ class _Progress:
             self.bar.update(n)
 
 
-class Pose2VideoPipeline:
-    _optional_components = []
-    _long = True
+class _PipelineBase:
+    """The slice of `diffusers.DiffusionPipeline` the reference pipeline relies on
+    (pipeline_pose2vid_long.py:36,58-70,368,458): used as the base class only where diffusers is not importable."""
 
-    def __init__(self, vae, image_encoder, reference_unet, denoising_unet, pose_guider, scheduler,
-                 image_proj_model=None, tokenizer=None, text_encoder=None):
-        self._names = []
-        self.register_modules(vae=vae, image_encoder=image_encoder, reference_unet=reference_unet,
-                              denoising_unet=denoising_unet, pose_guider=pose_guider, scheduler=scheduler,
-                              image_proj_model=image_proj_model, tokenizer=tokenizer, text_encoder=text_encoder)
-        self.vae_scale_factor = 2 ** (len(self.vae.config.block_out_channels) - 1)
-        from transformers import CLIPImageProcessor
-        self.clip_image_processor = CLIPImageProcessor()
-        self.ref_image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor, do_convert_rgb=True)
-        self.cond_image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor, do_convert_rgb=True,
-                                                      do_normalize=True)
-        self._progress_disabled = False
-        self._hip_vae = None
-
-    # -- DiffusionPipeline surface -------------------------------------------------------------------
     def register_modules(self, **kw):
+        names = self.__dict__.setdefault("_names", [])
         for k, v in kw.items():
             setattr(self, k, v)
-            if k not in self._names:
-                self._names.append(k)
+            if k not in names:
+                names.append(k)
 
     @property
     def components(self):
-        return {k: getattr(self, k) for k in self._names}
+        return {k: getattr(self, k) for k in self.__dict__.get("_names", [])}
 
     def to(self, *args, **kwargs):
         """`.to(device)`, `.to(device, dtype)`, `.to(dtype=...)` on every nn.Module component"""
@@ -173,30 +162,52 @@ class Pose2VideoPipeline:
                 dtype = a
             else:
                 device = a
-        for k in self._names:
-            m = getattr(self, k)
+        for m in self.components.values():
             if isinstance(m, torch.nn.Module):
                 m.to(device=device, dtype=dtype)
-        self._hip_vae = None
         return self
 
     @property
     def device(self):
-        for k in self._names:
-            m = getattr(self, k)
+        for m in self.components.values():
             if isinstance(m, torch.nn.Module):
                 return next(m.parameters()).device
         return torch.device("cpu")
 
+    def progress_bar(self, iterable=None, total=None):
+        return _Progress(total, bool(self.__dict__.get("_progress_bar_config", {}).get("disable", False)))
+
+    def set_progress_bar_config(self, **kw):
+        self.__dict__["_progress_bar_config"] = kw
+
+
+try:  # the reference's class is a diffusers.DiffusionPipeline (pipeline_pose2vid_long.py:36): keep that where it exists
+    from diffusers import DiffusionPipeline as _Base
+except Exception:  # diffusers is not part of the bare ROCm image
+    _Base = _PipelineBase
+
+
+class Pose2VideoPipeline(_Base):
+    _optional_components = []
+    _long = True
+
+    def __init__(self, vae, image_encoder, reference_unet, denoising_unet, pose_guider, scheduler,
+                 image_proj_model=None, tokenizer=None, text_encoder=None):
+        super().__init__()
+        self.register_modules(vae=vae, image_encoder=image_encoder, reference_unet=reference_unet,
+                              denoising_unet=denoising_unet, pose_guider=pose_guider, scheduler=scheduler,
+                              image_proj_model=image_proj_model, tokenizer=tokenizer, text_encoder=text_encoder)
+        self.vae_scale_factor = 2 ** (len(self.vae.config.block_out_channels) - 1)
+        from transformers import CLIPImageProcessor
+        self.clip_image_processor = CLIPImageProcessor()
+        self.ref_image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor, do_convert_rgb=True)
+        self.cond_image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor, do_convert_rgb=True,
+                                                      do_normalize=True)
+        self._hip_vae = None
+
     @property
     def _execution_device(self):
         return self.device
-
-    def progress_bar(self, iterable=None, total=None):
-        return _Progress(total, self._progress_disabled)
-
-    def set_progress_bar_config(self, **kw):
-        self._progress_disabled = bool(kw.get("disable", False))
 
     def enable_vae_slicing(self):
         self.vae.enable_slicing()
@@ -236,9 +247,12 @@ class Pose2VideoPipeline:
         """the HIP VAE; a foreign (diffusers) AutoencoderKL is adopted once via its state-dict"""
         if isinstance(self.vae, AutoencoderKL):
             return self.vae
-        if self._hip_vae is None:
-            self._hip_vae = AutoencoderKL.from_module(self.vae)
-        return self._hip_vae
+        src = self.vae
+        p = next(src.parameters())
+        tag = (id(src), str(p.device), p.dtype)
+        if self._hip_vae is None or self._hip_vae[0] != tag:
+            self._hip_vae = (tag, AutoencoderKL.from_module(src))
+        return self._hip_vae[1]
 
     def decode_latents(self, latents, decode_chunk=16):
         """latents (1, 4, L, h, w) -> numpy (1, 3, L, H, W) fp32 in [0, 1] (pipeline_pose2vid_long.py:113-126)"""
@@ -282,15 +296,23 @@ class Pose2VideoPipeline:
         a_p = float(sch.alphas_cumprod[prev]) if prev >= 0 else float(sch.final_alpha_cumprod)
         return math.sqrt(a_t), math.sqrt(max(1 - a_t, 0.0)), math.sqrt(a_p), math.sqrt(max(1 - a_p, 0.0))
 
+    max_cached_graphs = 4   # window shapes whose captured graph (+ private pool, static buffers) stay resident
+
     def _get_runners(self):
-        """{(S, f, h, w, device): _DenoiseRunner} — dropped whenever the denoising UNet re-packs its weights
-        (a captured graph has the packed tensors' addresses baked in)."""
+        """{(S, f, h, w, device): _DenoiseRunner}, least recently used first — dropped whenever the denoising UNet
+        re-packs its weights (a captured graph has the packed tensors' addresses baked in) and bounded to
+        `max_cached_graphs` entries (`drop_cached_graphs()` empties it)."""
         unet = self.denoising_unet
         tag = (id(unet), id(unet.packed()))
         if self.__dict__.get("_runner_tag") != tag:
             self.__dict__["_runner_tag"] = tag
-            self.__dict__["_runners"] = {}
+            self.__dict__["_runners"] = OrderedDict()
         return self.__dict__["_runners"]
+
+    def drop_cached_graphs(self):
+        """release every captured denoising graph and its static buffers"""
+        self.__dict__["_runners"] = OrderedDict()
+        self.__dict__.pop("_runner_tag", None)
 
     @staticmethod
     def _require_gpu(device):
@@ -379,6 +401,11 @@ class Pose2VideoPipeline:
         windows = [list(c) for c in windows_fn(L, num_inference_steps)]
         my_windows = D.shard_round_robin(len(windows), rank, ws) if ws > 1 else list(range(len(windows)))
         win_idx = {k: torch.tensor(windows[k], dtype=torch.int32, device=device) for k in my_windows}
+        # a dilated window can wrap onto a frame twice (context_stride > 1); the reference's index assignment
+        # `noise_pred[:, :, c] = noise_pred[:, :, c] + pred` then keeps the LAST occurrence and counts the frame once
+        # (pipeline_pose2vid_long.py:546-549): earlier duplicates are masked out (-1) for the accumulation
+        acc_idx = {k: torch.tensor(_last_occurrence_only(windows[k]), dtype=torch.int32, device=device)
+                   for k in my_windows}
         pose_cache = {}
 
         def pose_features(k):
@@ -416,6 +443,9 @@ class Pose2VideoPipeline:
                 r = runners.get(key)
                 if r is None or not r.matches(x0, ehs[:S], pose_features(k)):
                     r = runners[key] = _DenoiseRunner(self.denoising_unet, S, len(c), x0, ehs[:S], pose_features(k))
+                runners.move_to_end(key)
+                while len(runners) > max(1, int(self.max_cached_graphs)):
+                    runners.popitem(last=False)
                 r.set_clip(ehs[:S])
                 if single:
                     r.set_pose(pose_features(k))
@@ -435,8 +465,10 @@ class Pose2VideoPipeline:
                     pred = r.replay(x, temb_table[i]) if (use_graph and i >= 1) else r.eager(x, temb_table[i])
                     if i <= 1:
                         tm.mark(f"unet_step{i}" + ("(eager)" if not (use_graph and i >= 1) else "(graph)"))
-                    ops.window_accumulate(pred, acc, counter, win_idx[k], S, len(c), L, HWC)
-                if ws > 1 and len(windows) > 1:
+                    ops.window_accumulate(pred, acc, counter, acc_idx[k], S, len(c), L, HWC)
+                if ws > 1:
+                    # also for a single window: the ranks that own no window hold zeros (acc / counter = 0 / 0
+                    # otherwise), and every rank needs the step's latents for its share of the VAE decode
                     D.allreduce_window_sums(acc, counter, dp_group)
                 sa, sb, sap, sbp = self._fused_step_coefficients(t)
                 ops.cfg_ddim_step(acc, counter, lat32, lat16, S, L, HWC, guidance_scale, sa, sb, sap, sbp)
@@ -502,6 +534,12 @@ class Pose2VideoPipeline:
         return self._run(ref_image, pose_images, ref_pose_image, width, height, video_length, num_inference_steps,
                          guidance_scale, num_images_per_prompt, eta, generator, output_type, return_dict, callback,
                          callback_steps, windows_fn, **kwargs)
+
+
+def _last_occurrence_only(frames):
+    """frame indices with every occurrence but the last of a repeated frame replaced by -1"""
+    last = {f: j for j, f in enumerate(frames)}
+    return [f if last[f] == j else -1 for j, f in enumerate(frames)]
 
 
 def bank_shapes(unet_cfg, S, h, w):

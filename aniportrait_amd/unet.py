@@ -86,10 +86,9 @@ class _UNetBase(HipModel):
     def _invalidate(self):
         super()._invalidate()
         if "_attn2_cache" in self.__dict__:
-            self._attn2_cache.key = None
+            self._attn2_cache.drop()
             for rb in self._ref_blocks.values():
-                rb.state.bank = None
-                rb.state.kref = rb.state.vtref = None
+                rb.state.drop()
 
     # ------------------------------------------------------------------------------------------------
     def _engine_refs(self):
@@ -120,14 +119,16 @@ class _UNetBase(HipModel):
                 raise NotImplementedError(f"{type(self).__name__}.forward: `{k}` is not part of the pose2vid hot path")
 
     def forward_nhwc(self, x, b, f, timestep, encoder_hidden_states, pose_nhwc=None, final=True,
-                     stop_after_last_bank=False, temb_in=None):
+                     stop_after_last_bank=False, temb_in=None, attn2_refresh=True):
         """channels-last entry used by the pipeline: x (b*f, h, w, C) fp16 on the GPU.  temb_in: device fp32
-        (b, C0) timestep sinusoid replacing `timestep` (see engine.unet_forward)."""
+        (b, C0) timestep sinusoid replacing `timestep` (see engine.unet_forward).  attn2_refresh=False: reuse the
+        collapsed-attn2 vectors the previous forward computed for this batch size (engine.Attn2Cache)."""
         net = self.packed()
         refs = self._engine_refs()
         ridx = self._ref_index(b, f, refs, net.device)
         out = engine.unet_forward(net, self.config, x, b, f, timestep, encoder_hidden_states, self._attn2_cache,
-                                  refs, self.three_d, ridx, pose_nhwc, final, stop_after_last_bank, temb_in)
+                                  refs, self.three_d, ridx, pose_nhwc, final, stop_after_last_bank, temb_in,
+                                  attn2_refresh)
         for p, rb in self._ref_blocks.items():  # write mode: append to module.bank like the hacked forward
             if rb.state.mode == "write" and rb.state.written is not None:
                 rb.node.bank.append(rb.state.written)

@@ -5,7 +5,7 @@ how golden fixtures are produced (`oracle/make_golden.py`) and how `oracle/ref_t
 validated.  Never imported by the product.
 
 Parity status: the reference files run unmodified, but `diffusers==0.24.0` underneath is a
-restatement => "parity unpinned" at that boundary (see oracle/README.md).
+restatement => "parity unpinned" at that boundary (see oracle/diffusers_stub/README.md).
 """
 import os
 import sys
@@ -34,17 +34,34 @@ def setup():
         tv.transforms = tvt
         sys.modules["torchvision"] = tv
         sys.modules["torchvision.transforms"] = tvt
+    # the reference's checkout must come BEFORE this repository on sys.path: both hold a `src/` namespace package
+    # (no __init__.py on either side), so path order decides which `src.models.*` / `src.pipelines.*` files win
     for p in (_STUB, REFERENCE_ROOT):
-        if p not in sys.path:
-            sys.path.insert(0, p)
+        while p in sys.path:
+            sys.path.remove(p)
+        sys.path.insert(0, p)
     if _REPO not in sys.path:
         sys.path.append(_REPO)
-    # the repo ships its own `src/` drop-in shim; make sure the reference's `src` wins here
+    # drop whatever `src*` modules were imported before (e.g. the repo's drop-in shim)
     for k in [k for k in sys.modules if k == "src" or k.startswith("src.")]:
-        m = sys.modules[k]
-        f = getattr(m, "__file__", "") or ""
+        f = getattr(sys.modules[k], "__file__", None) or ""
         if not f.startswith(REFERENCE_ROOT):
             del sys.modules[k]
+    import importlib
+    importlib.invalidate_caches()
+    assert_reference("src.pipelines.context")
+
+
+def assert_reference(*module_names):
+    """every named module must resolve to a file under REFERENCE_ROOT — guards the golden recipe against silently
+    comparing the product with itself"""
+    import importlib
+    for name in module_names:
+        m = importlib.import_module(name)
+        f = getattr(m, "__file__", None) or ""
+        if not os.path.abspath(f).startswith(os.path.abspath(REFERENCE_ROOT) + os.sep):
+            raise RuntimeError(f"oracle/ref_harness: `{name}` resolved to {f!r}, not to the reference under "
+                               f"{REFERENCE_ROOT} — refusing to produce 'reference' outputs from the product's own code")
 
 
 def build_models(small=True, seed=0, with_clip=True, dtype=None):
@@ -55,6 +72,8 @@ def build_models(small=True, seed=0, with_clip=True, dtype=None):
     from src.models.pose_guider import PoseGuider
     from src.models.unet_2d_condition import UNet2DConditionModel
     from src.models.unet_3d import UNet3DConditionModel
+    assert_reference("src.models.pose_guider", "src.models.unet_2d_condition", "src.models.unet_3d",
+                     "src.models.mutual_self_attention")
 
     from aniportrait_amd import configs as C
     from aniportrait_amd.synthetic import fill_module_

@@ -188,8 +188,9 @@ def add(a, b):
 
 def window_accumulate(pred, acc, counter, frames, S, Fw, L_, HWC):
     idx = frames.long()
-    acc.view(S, L_, HWC)[:, idx] += pred.float().reshape(S, Fw, HWC)
-    counter[idx] += 1.0
+    keep = idx >= 0                      # masked slots (earlier duplicates of a wrapped dilated window) are skipped
+    acc.view(S, L_, HWC)[:, idx[keep]] += pred.float().reshape(S, Fw, HWC)[:, keep]
+    counter[idx[keep]] += 1.0
 
 
 def cfg_ddim_step(acc, counter, latents, latents_f16, S, L_, HWC, guidance, sa, sb, sap, sbp):

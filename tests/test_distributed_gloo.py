@@ -94,7 +94,7 @@ class _Patch:
         setattr(obj, name, value)
 
 
-def _pipeline_worker(rank, world, port, q):
+def _pipeline_worker(rank, world, port, q, case):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import sys
@@ -111,7 +111,9 @@ def _pipeline_worker(rank, world, port, q):
         from src.pipelines.pipeline_pose2vid_long import Pose2VideoPipeline
         from util import build_hip_models, load_golden, psnr, small_clip_encoder
         m, _ = build_hip_models(True, device="cpu")
-        i = pipe_inputs("long_L10_ctx8")       # L = 10, 8-frame windows: two windows per step -> one per rank
+        # long_L10_ctx8: L = 10, 8-frame windows: two windows per step -> one per rank
+        # long_L4:       ONE window: rank 1 owns none (its sums stay zero) and still decodes its share of the frames
+        i = pipe_inputs(case)
         pipe = Pose2VideoPipeline(vae=m["vae"], image_encoder=small_clip_encoder("cpu"), reference_unet=m["reference_unet"],
                                   denoising_unet=m["denoising_unet"], pose_guider=m["pose_guider"],
                                   scheduler=DDIMScheduler(**C.DDIM_V2))
@@ -124,27 +126,29 @@ def _pipeline_worker(rank, world, port, q):
                    latents=i["latents"], dp_group=dist.group.WORLD, **i["kw"])
         if rank == 0:
             gold = load_golden("small_pipeline.pt")
-            q.put((rank, float(psnr(out.videos, gold["long_L10_ctx8/video_f16"].float())), tuple(out.videos.shape)))
+            q.put((rank, float(psnr(out.videos, gold[case + "/video_f16"].float())), tuple(out.videos.shape)))
         else:
             q.put((rank, out is None, None))
     finally:
         dist.destroy_process_group()
 
 
-def test_two_rank_long_clip_pipeline_matches_reference():
+@pytest.mark.parametrize("case,L", [("long_L10_ctx8", 10), ("long_L4", 4)])
+def test_two_rank_long_clip_pipeline_matches_reference(case, L):
     """One long clip on 2 ranks (gloo, CPU, kernel wrappers emulated — tests/emu_hipops.py): windows sharded round
     robin, rank 0's ReferenceNet banks broadcast, per-step all-reduce of the window sums, frames decoded per rank
-    and gathered — the decoded video on rank 0 matches the reference's single-process pipeline."""
+    and gathered — the decoded video on rank 0 matches the reference's single-process pipeline.  The single-window
+    case covers a rank without any window (round 1 produced 0/0 = NaN latents there)."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, q, case)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=600) for _ in range(world))
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    assert res[0][0] == 0 and res[0][1] >= 40.0 and res[0][2] == (1, 3, 10, 128, 128), res
+    assert res[0][0] == 0 and res[0][1] >= 40.0 and res[0][2] == (1, 3, L, 128, 128), res
     assert res[1][0] == 1 and res[1][1] is True, res

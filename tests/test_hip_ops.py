@@ -398,6 +398,29 @@ def test_window_accumulate_and_ddim():
     close(lat16, ref, "cfg+ddim step fp16 copy")
 
 
+def test_window_accumulate_wrapped_dilated_window():
+    """a dilated window that wraps onto a frame twice (L=20, 16 frames, stride 2 -> 0,2,..,18,0,2,..,10): the
+    reference's `noise_pred[:, :, c] = noise_pred[:, :, c] + pred` keeps the LAST occurrence and counts the frame once
+    (pipeline_pose2vid_long.py:546-549); the host masks the earlier ones, the kernel skips masked slots"""
+    from aniportrait_amd.pipeline_pose2vid_long import _last_occurrence_only
+    ops = _ops()
+    S, L, HWC = 2, 20, 4 * 4 * 4
+    frames = [(2 * j) % L for j in range(16)]
+    assert len(set(frames)) < len(frames)
+    pred = rnd(S, 16, HWC, seed=7)
+    ref_acc = torch.zeros(S, L, HWC)
+    ref_cnt = torch.zeros(L)
+    ref_acc[:, frames] = ref_acc[:, frames] + pred.float()     # the reference's statement, on the CPU
+    ref_cnt[frames] = ref_cnt[frames] + 1
+    acc = torch.zeros(S, L, HWC, device=DEV)
+    counter = torch.zeros(L, device=DEV)
+    fi = torch.tensor(_last_occurrence_only(frames), dtype=torch.int32, device=DEV)
+    for _ in range(3):                                          # deterministic: no two threads share an element
+        acc.zero_(); counter.zero_()
+        ops.window_accumulate(pred.to(DEV), acc, counter, fi, S, 16, L, HWC)
+        assert torch.equal(acc.cpu(), ref_acc) and torch.equal(counter.cpu(), ref_cnt)
+
+
 # ------------------------------------------------------------------------------------------------
 # gemm2 (the main 256 x BN LDS-DMA kernel): problems large enough to be dispatched to it (M >= 1024 and
 # >= 128 tiles), every loader / epilogue variant, ragged M / N / K tails

@@ -129,3 +129,25 @@ def test_reference_attention_control_protocol():
     assert modes["down_blocks.0.attentions.0"] == "plain" and modes["mid_block.attentions.0"] == "read"
     with pytest.raises(AssertionError):
         RAC(u3, mode="both")
+
+
+def test_wrapped_dilated_window_accumulates_like_the_reference(monkeypatch):
+    """context_stride > 1 can make a window visit a frame twice; the accumulation must equal the reference's index
+    assignment (last occurrence wins, frame counted once) — host-side masking + the (emulated) kernel's skip rule"""
+    import emu_hipops
+    from aniportrait_amd.context import uniform
+    from aniportrait_amd.pipeline_pose2vid_long import _last_occurrence_only
+    L, S, HWC = 20, 2, 12
+    windows = [list(w) for w in uniform(0, 25, L, 16, 2, 4)]
+    assert any(len(set(w)) < len(w) for w in windows)           # the case exists with the reference's scheduler
+    g = torch.Generator().manual_seed(3)
+    acc, cnt = torch.zeros(S, L, HWC), torch.zeros(L)
+    ref_acc, ref_cnt = torch.zeros(S, L, HWC), torch.zeros(L)
+    for w in windows:
+        pred = torch.randn((S, len(w), HWC), generator=g).half()
+        ref_acc[:, w] = ref_acc[:, w] + pred.float()
+        ref_cnt[w] = ref_cnt[w] + 1
+        emu_hipops.window_accumulate(pred, acc, cnt, torch.tensor(_last_occurrence_only(w), dtype=torch.int32), S,
+                                     len(w), L, HWC)
+    assert torch.equal(acc, ref_acc) and torch.equal(cnt, ref_cnt)
+    assert _last_occurrence_only([0, 2, 4, 0, 2]) == [-1, -1, 4, 0, 2]
