@@ -11,6 +11,8 @@
 //    transpose — only a fixed permutation of the 16-key groups that matches the accumulator layout.
 // 2. temporal_attn_kernel: attention over the F (<= 32) frames of one pixel & head; purely HBM-bound
 //    strided gather, one wave per problem, everything staged in LDS.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -47,6 +49,13 @@ __device__ __forceinline__ unsigned int pk_f16(float a, float b) {
   return t.u;
 }
 
+// max(x[lane], x[lane ^ 32]) with one v_permlane32_swap (lanes 32..63 of the first operand <-> lanes 0..31 of the
+// second) instead of a ds_bpermute round trip through the LDS on the softmax's critical path
+__device__ __forceinline__ float xor32_max(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 // Online softmax is the VALU-bound part of this kernel at d = 40 (rocprofv3: SQ_ACTIVE_INST_VALU 88 % of the
 // kernel's cycles vs 23 % MFMA busy before this restructuring), so the per-score VALU work is cut to
 // max3 / fma / v_exp / cvt_pk:
@@ -58,7 +67,13 @@ constexpr float RESCALE_LOG2 = 8.0f;
 
 // FAST: T % 64 == 0 and 16-B aligned V^T rows (every C2 shape): no key masking, branch-free 16-B loads with
 // 32-bit per-thread offsets from a wave-uniform base.
-template <int D, bool FAST>
+// QH: 32-query groups per wave (1 or 2).  With QH = 2 a wave owns 64 queries: every K / V^T fragment read from LDS
+// feeds two MFMAs, and the two groups are independent dependency chains issued in the order
+//   QK(0) QK(1) | softmax(0) | PV(0) | softmax(1) | PV(1)
+// so group 1's score MFMAs run in the matrix pipe under group 0's exponentials and group 0's P V MFMAs under group
+// 1's: the in-order wave overlaps its own VALU and MFMA work instead of relying on a co-resident wave being in the
+// other phase (measured on the QH = 1 kernel at d = 40: per-tile SIMD time = VALU time + MFMA time, i.e. no overlap).
+template <int D, bool FAST, int QH>
 __global__ __launch_bounds__(NT, (D > 96 ? 1 : 2)) void ref_attn_kernel(const RefAttnArgs a) {
   constexpr int DQ = (D + 15) / 16;        // 16-wide contraction chunks of Q K^T
   constexpr int DO = (D + 31) / 32;        // 32-row output tiles of O^T
@@ -68,6 +83,7 @@ __global__ __launch_bounds__(NT, (D > 96 ? 1 : 2)) void ref_attn_kernel(const Re
   constexpr bool ONES = (D % 32) != 0;     // spare padded V^T row available for the denominator
   constexpr int LT = D / 32, LR = D % 32;  // O^T tile / row of the ones-row
   constexpr int L_HI = (LR >> 2) & 1, L_REG = 4 * (LR >> 3) + (LR & 3);
+  constexpr int QPB = 128 * QH;            // queries per block
   static_assert(D % 8 == 0, "head dim must be a multiple of 8");
   __shared__ __attribute__((aligned(16))) f16 sK[2][KV * KROW];
   __shared__ __attribute__((aligned(16))) f16 sV[2][DO * 32 * VROW];
@@ -76,8 +92,13 @@ __global__ __launch_bounds__(NT, (D > 96 ? 1 : 2)) void ref_attn_kernel(const Re
   const int ql = lane & 31, hi = lane >> 5;
   const int T = a.T;
   const int h = blockIdx.y, n = blockIdx.z;
-  const int q = blockIdx.x * 128 + wave * 32 + ql;
-  const bool qvalid = q < T;
+  int q[QH];
+  bool qvalid[QH];
+#pragma unroll
+  for (int g = 0; g < QH; ++g) {
+    q[g] = blockIdx.x * QPB + wave * (32 * QH) + g * 32 + ql;
+    qvalid[g] = q[g] < T;
+  }
   const int ref = a.ref_index ? a.ref_index[n] : -1;
 
   // zero the padding that is never overwritten: K columns [D, DQ*16) and V^T rows [D, DO*32)
@@ -89,16 +110,17 @@ __global__ __launch_bounds__(NT, (D > 96 ? 1 : 2)) void ref_attn_kernel(const Re
   }
 
   // Q fragments (B operand of S^T = K Q^T): lane (q = ql, hi) holds Q[q][16 kk + 8 hi .. +7]
-  f16x8 qf[DQ];
-  {
-    const f16* qp = a.q + ((int64_t)n * T + (qvalid ? q : 0)) * a.ldq + h * D;
+  f16x8 qf[QH][DQ];
+#pragma unroll
+  for (int g = 0; g < QH; ++g) {
+    const f16* qp = a.q + ((int64_t)n * T + (qvalid[g] ? q[g] : 0)) * a.ldq + h * D;
 #pragma unroll
     for (int kk = 0; kk < DQ; ++kk) {
       const int d0 = kk * 16 + hi * 8;
       U4H8 t;
       t.u = u32x4{0u, 0u, 0u, 0u};
-      if (qvalid && d0 < D) t.u = *(const u32x4*)(qp + d0);
-      qf[kk] = t.h;
+      if (qvalid[g] && d0 < D) t.u = *(const u32x4*)(qp + d0);
+      qf[g][kk] = t.h;
     }
   }
 
@@ -180,13 +202,18 @@ __global__ __launch_bounds__(NT, (D > 96 ? 1 : 2)) void ref_attn_kernel(const Re
     }
   };
 
-  f32x16 o[DO];
+  f32x16 o[QH][DO];
+  float m_run[QH];           // reference max of the exponent (raised lazily), raw-score units
+  float l_run[QH];           // denominator when there is no spare V^T row (!ONES)
 #pragma unroll
-  for (int dt = 0; dt < DO; ++dt)
+  for (int g = 0; g < QH; ++g) {
+    m_run[g] = -INFINITY;
+    l_run[g] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
-  float m_run = -INFINITY;   // reference max of the exponent (raised lazily), raw-score units
-  float l_run = 0.f;         // denominator when there is no spare V^T row (!ONES)
+    for (int dt = 0; dt < DO; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[g][dt][r] = 0.f;
+  }
   const float c2 = a.scale_log2e;
   const int ka_off = ql * KROW + hi * 8;
   const int va_off = ql * VROW + hi * 8;
@@ -200,112 +227,140 @@ __global__ __launch_bounds__(NT, (D > 96 ? 1 : 2)) void ref_attn_kernel(const Re
     const bool more = (t + 1) < ntiles;
     if (more) load_tile(t + 1);
 
-    // ---- S^T = K Q^T : two 32-key x 32-query tiles -------------------------------------------
-    f32x16 s0, s1;
+    // ---- S^T = K Q^T : two 32-key x 32-query tiles per query group ---------------------------------
+    f32x16 s0[QH], s1[QH];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
+    for (int g = 0; g < QH; ++g)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s0[g][r] = s1[g][r] = 0.f;
     const f16* kbuf = &sK[buf][ka_off];
 #pragma unroll
     for (int kk = 0; kk < DQ; ++kk) {
       const f16x8 a0 = *(const f16x8*)(kbuf + kk * 16);
       const f16x8 a1 = *(const f16x8*)(kbuf + 32 * KROW + kk * 16);
-      s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, qf[kk], s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, qf[kk], s1, 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < QH; ++g) {
+        s0[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, qf[g][kk], s0[g], 0, 0, 0);
+        s1[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, qf[g][kk], s1[g], 0, 0, 0);
+      }
     }
     // mask keys beyond the segment length (last tile of a segment only)
     const int tt = t >= nts ? t - nts : t;
     if (!FAST && tt * KV + KV > T) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = tt * KV + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (key >= T) s0[r] = -INFINITY;
-        if (key + 32 >= T) s1[r] = -INFINITY;
-      }
+      for (int g = 0; g < QH; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = tt * KV + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key >= T) s0[g][r] = -INFINITY;
+          if (key + 32 >= T) s1[g][r] = -INFINITY;
+        }
     }
-    // ---- online softmax (one query per lane; partner lane^32 holds the other 32 keys) ------------
-    float mx = fmaxf(fmaxf(s0[0], s0[1]), s0[2]);
-#pragma unroll
-    for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s0[r]), s0[r + 1]);
-    mx = fmaxf(fmaxf(mx, s0[15]), s1[0]);
-#pragma unroll
-    for (int r = 1; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s1[r]), s1[r + 1]);
-    mx = fmaxf(mx, s1[15]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    if (__any((mx - m_run) * c2 > RESCALE_LOG2)) {   // wave-uniform; always taken on the first tile
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = fast_exp2((m_run - m_new) * c2);
-      m_run = m_new;
-      l_run *= alpha;
-#pragma unroll
-      for (int dt = 0; dt < DO; ++dt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-    }
-    const float mb = m_run * c2;
-    // P^T fragments (B operand): k-slot (hi, j) of 16-key group g <-> accumulator reg 8*(g&1)+j of tile g>>1
-    U4H8 pb[4];
-#pragma unroll
-    for (int j = 0; j < 8; j += 2) {
-      const float p00 = fast_exp2(fmaf(s0[j], c2, -mb)), p01 = fast_exp2(fmaf(s0[j + 1], c2, -mb));
-      const float p10 = fast_exp2(fmaf(s0[8 + j], c2, -mb)), p11 = fast_exp2(fmaf(s0[9 + j], c2, -mb));
-      const float p20 = fast_exp2(fmaf(s1[j], c2, -mb)), p21 = fast_exp2(fmaf(s1[j + 1], c2, -mb));
-      const float p30 = fast_exp2(fmaf(s1[8 + j], c2, -mb)), p31 = fast_exp2(fmaf(s1[9 + j], c2, -mb));
-      if (!ONES) l_run += ((p00 + p01) + (p10 + p11)) + ((p20 + p21) + (p30 + p31));
-      pb[0].u[j >> 1] = pk_f16(p00, p01);
-      pb[1].u[j >> 1] = pk_f16(p10, p11);
-      pb[2].u[j >> 1] = pk_f16(p20, p21);
-      pb[3].u[j >> 1] = pk_f16(p30, p31);
-    }
-    // ---- O^T += V^T P^T ------------------------------------------------------------------------
+    // V^T fragments of the tile (A operand of O^T += V^T P^T), shared by the query groups
     const f16* vbuf = &sV[buf][va_off];
 #pragma unroll
-    for (int dt = 0; dt < DO; ++dt) {
+    for (int g = 0; g < QH; ++g) {
+      // ---- online softmax (one query per lane; partner lane^32 holds the other 32 keys) ------------
+      float mx = fmaxf(fmaxf(s0[g][0], s0[g][1]), s0[g][2]);
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f16x8 av = *(const f16x8*)(vbuf + dt * 32 * VROW + g * 16);
-        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, pb[g].h, o[dt], 0, 0, 0);
+      for (int r = 3; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s0[g][r]), s0[g][r + 1]);
+      mx = fmaxf(fmaxf(mx, s0[g][15]), s1[g][0]);
+#pragma unroll
+      for (int r = 1; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s1[g][r]), s1[g][r + 1]);
+      mx = fmaxf(mx, s1[g][15]);
+      mx = xor32_max(mx);
+      if (__any((mx - m_run[g]) * c2 > RESCALE_LOG2)) {   // wave-uniform; always taken on the first tile
+        const float m_new = fmaxf(m_run[g], mx);
+        const float alpha = fast_exp2((m_run[g] - m_new) * c2);
+        m_run[g] = m_new;
+        l_run[g] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DO; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[g][dt][r] *= alpha;
       }
+      const float mb = m_run[g] * c2;
+      // P^T fragments (B operand): k-slot (hi, j) of 16-key group gk <-> accumulator reg 8*(gk&1)+j of tile gk>>1
+      U4H8 pb[4];
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        const float p00 = fast_exp2(fmaf(s0[g][j], c2, -mb)), p01 = fast_exp2(fmaf(s0[g][j + 1], c2, -mb));
+        const float p10 = fast_exp2(fmaf(s0[g][8 + j], c2, -mb)), p11 = fast_exp2(fmaf(s0[g][9 + j], c2, -mb));
+        const float p20 = fast_exp2(fmaf(s1[g][j], c2, -mb)), p21 = fast_exp2(fmaf(s1[g][j + 1], c2, -mb));
+        const float p30 = fast_exp2(fmaf(s1[g][8 + j], c2, -mb)), p31 = fast_exp2(fmaf(s1[g][9 + j], c2, -mb));
+        if (!ONES) l_run[g] += ((p00 + p01) + (p10 + p11)) + ((p20 + p21) + (p30 + p31));
+        pb[0].u[j >> 1] = pk_f16(p00, p01);
+        pb[1].u[j >> 1] = pk_f16(p10, p11);
+        pb[2].u[j >> 1] = pk_f16(p20, p21);
+        pb[3].u[j >> 1] = pk_f16(p30, p31);
+      }
+      if (QH > 1) __builtin_amdgcn_sched_barrier(0);   // keep this group's P V MFMAs ahead of the next group's softmax
+      // ---- O^T += V^T P^T ----------------------------------------------------------------------
+#pragma unroll
+      for (int dt = 0; dt < DO; ++dt) {
+#pragma unroll
+        for (int gk = 0; gk < 4; ++gk) {
+          const f16x8 av = *(const f16x8*)(vbuf + dt * 32 * VROW + gk * 16);
+          o[g][dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, pb[gk].h, o[g][dt], 0, 0, 0);
+        }
+      }
+      if (QH > 1) __builtin_amdgcn_sched_barrier(0);
     }
     if (more) store_tile(buf ^ 1);
     __syncthreads();
   }
 
   // ---- epilogue -------------------------------------------------------------------------------------
-  float l_tot;
-  if (ONES) {
-    const float lv = o[LT][L_REG];                 // row D of O^T: held by the half-wave with hi == L_HI
-    const float lp = __shfl_xor(lv, 32, 64);
-    l_tot = (hi == L_HI) ? lv : lp;
-  } else {
-    l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  }
-  const float inv = 1.0f / l_tot;
-  if (qvalid) {
-    f16* op = a.out + ((int64_t)n * T + q) * a.ldo + h * D;
 #pragma unroll
-    for (int dt = 0; dt < DO; ++dt)
+  for (int g = 0; g < QH; ++g) {
+    float l_tot;
+    if (ONES) {
+      const float lv = o[g][LT][L_REG];              // row D of O^T: held by the half-wave with hi == L_HI
+      const float lp = __shfl_xor(lv, 32, 64);
+      l_tot = (hi == L_HI) ? lv : lp;
+    } else {
+      l_tot = l_run[g] + __shfl_xor(l_run[g], 32, 64);
+    }
+    const float inv = 1.0f / l_tot;
+    if (qvalid[g]) {
+      f16* op = a.out + ((int64_t)n * T + q[g]) * a.ldo + h * D;
 #pragma unroll
-      for (int rq = 0; rq < 4; ++rq) {
-        const int d0 = dt * 32 + rq * 8 + hi * 4;
-        if (d0 < D) {
-          f16x4 v;
+      for (int dt = 0; dt < DO; ++dt)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = (f16)(o[dt][rq * 4 + e] * inv);
-          *(f16x4*)(op + d0) = v;
+        for (int rq = 0; rq < 4; ++rq) {
+          const int d0 = dt * 32 + rq * 8 + hi * 4;
+          if (d0 < D) {
+            f16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (f16)(o[g][dt][rq * 4 + e] * inv);
+            *(f16x4*)(op + d0) = v;
+          }
         }
-      }
+    }
   }
 }
 
+// query groups per wave: 2 where the head dim leaves the registers for it (d <= 64) and the frame has enough query
+// blocks to fill the chip either way; ANIP_ATTN_QH=1|2 overrides (kernel experiments)
 template <int D>
 int launch_ref_attn(const RefAttnArgs& a, int Nf, hipStream_t stream) {
-  dim3 grid((unsigned)((a.T + 127) / 128), (unsigned)a.heads, (unsigned)Nf);
+  static const int force_qh = getenv("ANIP_ATTN_QH") ? atoi(getenv("ANIP_ATTN_QH")) : 0;
+  constexpr bool CAN2 = D <= 64;
+  const bool two = CAN2 && (force_qh ? force_qh == 2 : (a.T >= 1024));
+  dim3 grid((unsigned)((a.T + (two ? 255 : 127)) / (two ? 256 : 128)), (unsigned)a.heads, (unsigned)Nf);
   AnipProfScope prof_(ANIP_K_REF_ATTN, (void*)stream);
   const bool fits32 = (int64_t)KV * a.ldk < (1ll << 31) && (int64_t)KV * a.ldkr < (1ll << 31) &&
                       (int64_t)(D + 32) * a.ldvt < (1ll << 31) && (int64_t)(D + 32) * a.ldvtr < (1ll << 31);
   const bool fast = (a.T % KV) == 0 && a.vt_vec_ok && (a.ref_index == nullptr || a.vtref_vec_ok) && fits32;
-  if (fast) hipLaunchKernelGGL((ref_attn_kernel<D, true>), grid, dim3(NT), 0, stream, a);
-  else hipLaunchKernelGGL((ref_attn_kernel<D, false>), grid, dim3(NT), 0, stream, a);
+  if constexpr (CAN2) {
+    if (two) {
+      if (fast) hipLaunchKernelGGL((ref_attn_kernel<D, true, 2>), grid, dim3(NT), 0, stream, a);
+      else hipLaunchKernelGGL((ref_attn_kernel<D, false, 2>), grid, dim3(NT), 0, stream, a);
+      return 0;
+    }
+  }
+  if (fast) hipLaunchKernelGGL((ref_attn_kernel<D, true, 1>), grid, dim3(NT), 0, stream, a);
+  else hipLaunchKernelGGL((ref_attn_kernel<D, false, 1>), grid, dim3(NT), 0, stream, a);
   return 0;
 }
 

@@ -197,6 +197,27 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
   for (int i = 0; i < FM; ++i)
 #pragma unroll
     for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // "tight" blocks — tile fully inside the output, 16-B accessible operands, alpha == 1: every hot shape of the path —
+  // start the accumulators from the per-column additive terms (bias and, when the block's rows share one row group,
+  // the row-group bias): NB small L2-resident loads that travel with the prologue DMA, no registers, and nothing
+  // left to fetch for them in the epilogue, where loads queue behind the tile's stores (see there).
+  const bool acc_has_bias = !TRANS && !(dbg & 8) && splitk <= 1 && p.alpha == 1.0f && m0 + BM2 <= p.M && n0 + BN <= p.N &&
+                            (p.bias != nullptr || p.rowbias != nullptr) &&
+                            (p.rowbias == nullptr || (((p.ld_rowbias & 3) == 0) && ((((uintptr_t)p.rowbias) & 15) == 0)));
+  const bool rb_uni = acc_has_bias && p.rowbias != nullptr &&
+                      (m0 / p.rows_per_group == (m0 + BM2 - 1) / p.rows_per_group);
+  if (!TRANS && acc_has_bias) {
+    const int cb = n0 + wn * WTN + (lane >> 4) * 4;          // column of acc[.][0][0] in this lane
+    const float* rb_row = rb_uni ? p.rowbias + (int64_t)(m0 / p.rows_per_group) * p.ld_rowbias : nullptr;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.bias != nullptr) b = *(const f32x4*)(p.bias + cb + j * 16);
+      if (rb_uni) b += *(const f32x4*)(rb_row + cb + j * 16);
+#pragma unroll
+      for (int i = 0; i < FM; ++i) acc[i][j] = b;
+    }
+  }
 
   // K-tile range of this block: all of K, or — split-K, blockIdx.y = slice — one of `splitk` contiguous slices whose
   // fp32 partial tile goes to the workspace (the batch offset of the epilogue) and is reduced by splitk_reduce_kernel
@@ -418,10 +439,16 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
 
   if (TRANS) {
     // out[n][m], m contiguous: pair the tiles (i, i+1) along M; bias only (checked by the launcher)
+    float bt[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {       // all bias loads in front of the first store
+      const int n = n0 + wn * WTN + j * 16 + fr;
+      bt[j] = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
+    }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
       const int n = n0 + wn * WTN + j * 16 + fr;
-      const float bn_ = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
+      const float bn_ = bt[j];
 #pragma unroll
       for (int ip = 0; ip < FM / 2; ++ip) {
         float x[4], y[4];
@@ -457,7 +484,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
       float bv0[4], bg0[4], bv1[4], bg1[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const bool hb = p.bias != nullptr;
+        const bool hb = p.bias != nullptr && !acc_has_bias;
         bv0[r] = (hb && pn + r < p.N) ? p.bias[pn + r] : 0.f;
         bg0[r] = (hb && pn + 16 + r < p.N) ? p.bias[pn + 16 + r] : 0.f;
         bv1[r] = (hb && pn + 32 + r < p.N) ? p.bias[pn + 32 + r] : 0.f;
@@ -479,30 +506,137 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
       }
     }
   } else {
+    // A block whose tile lies fully inside the output and whose operands allow 16-B accesses (every hot shape of the
+    // path) takes the tight epilogue below; ragged tiles take the general per-element-guarded one.
+    const bool has_rb = p.rowbias != nullptr, has_res = p.residual != nullptr;
+    const bool tight = !(dbg & 8) && p.alpha == 1.0f && m0 + BM2 <= p.M && n0 + BN <= p.N &&
+                       (p.out_f32 ? (p.ldo & 3) == 0 : (p.ldo & 7) == 0) && (!has_res || (p.ldr & 7) == 0) &&
+                       (acc_has_bias || (p.bias == nullptr && !has_rb)) &&
+                       (int64_t)p.M * p.ldo * 4 < (1ll << 32) && (!has_res || (int64_t)p.M * p.ldr * 2 < (1ll << 32));
+    if (!tight) {
 #pragma unroll
-    for (int jp = 0; jp < NB / 2; ++jp) {
-      const int n = n0 + wn * WTN + (2 * jp + tsel) * 16 + csel;
+      for (int jp = 0; jp < NB / 2; ++jp) {
+        const int n = n0 + wn * WTN + (2 * jp + tsel) * 16 + csel;
 #pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        float v[8];
+        for (int i = 0; i < FM; ++i) {
+          float v[8];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float x = acc[i][2 * jp][r] * alpha, y = acc[i][2 * jp + 1][r] * alpha;
-          row_swap(x, y);
-          v[r] = x;
-          v[4 + r] = y;
+          for (int r = 0; r < 4; ++r) {
+            float x = acc[i][2 * jp][r] * alpha, y = acc[i][2 * jp + 1][r] * alpha;
+            row_swap(x, y);
+            v[r] = x;
+            v[4 + r] = y;
+          }
+          emit8(m0 + wm * WTM + i * 16 + fr, n, p.N, v, true);
         }
-        emit8(m0 + wm * WTM + i * 16 + fr, n, p.N, v, true);
       }
-    }
-    if (NB & 1) {
-      const int n = n0 + wn * WTN + (NB - 1) * 16 + fq * 4;
+      if (NB & 1) {
+        const int n = n0 + wn * WTN + (NB - 1) * 16 + fq * 4;
 #pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        float v[4];
+        for (int i = 0; i < FM; ++i) {
+          float v[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = acc[i][NB - 1][r] * alpha;
-        emit4(m0 + wm * WTM + i * 16 + fr, n, v);
+          for (int r = 0; r < 4; ++r) v[r] = acc[i][NB - 1][r] * alpha;
+          emit4(m0 + wm * WTM + i * 16 + fr, n, v);
+        }
+      }
+    } else {
+      // Residual vectors in batches AHEAD of the stores.  `out` may alias anything as far as the compiler knows, so a
+      // load written after a store stays after it: fetched where they are used (the general path), every (row block,
+      // column pair) pays a dependent L2 / HBM round trip behind the previous stores — FM * NB/2 of them per wave with
+      // one KiB in flight each, which capped the K = 320 / 640 layers at ~2.5 TB/s.  Here RBAT residual vectors of a
+      // column pair are in flight together before the first of their stores; bias and block-uniform row-group bias
+      // are already inside the accumulators.  (RBAT: what the 128-VGPR budget of the 4-waves-per-SIMD tiles allows.)
+      constexpr int RBAT = (NW == 8 && WNW == 2 && NB == 5) ? 2 : FM;   // 256 x 160, 4 waves per SIMD: 128 VGPRs
+      // addressing: wave-uniform 64-bit bases (+ the uniform 16-row step) in SGPRs, one 32-bit per-lane BYTE offset —
+      // 64-bit per-lane pointers for every (row block, column pair) do not fit the 128-VGPR budget next to the
+      // accumulators
+      const int mrow = m0 + wm * WTM + fr;                 // row of acc[0][.]; tile i is 16 rows further down
+      const uint32_t esz = p.out_f32 ? 4u : 2u;
+      const uint32_t ldr_b = (uint32_t)p.ldr * 2u, ldo_b = (uint32_t)p.ldo * esz;
+      const char* resb = (const char*)p.residual;
+      char* outb = (char*)p.out + obatch * (int64_t)esz;
+      const uint32_t rrow = (uint32_t)mrow * ldr_b, orow = (uint32_t)mrow * ldo_b;
+      const bool rb_row = has_rb && !rb_uni;               // row-group bias that changes inside the block (rare)
+#pragma unroll
+      for (int jp = 0; jp < NB / 2; ++jp) {
+        const int n = n0 + wn * WTN + (2 * jp + tsel) * 16 + csel;
+        const uint32_t rn = rrow + (uint32_t)n * 2u, on = orow + (uint32_t)n * esz;
+#pragma unroll
+        for (int ib = 0; ib < FM; ib += RBAT) {
+          U4H8 res[RBAT];
+          if (has_res) {
+#pragma unroll
+            for (int i = 0; i < RBAT; ++i) res[i].u = *(const u32x4*)(resb + (size_t)((ib + i) * 16) * ldr_b + rn);
+          }
+#pragma unroll
+          for (int ii = 0; ii < RBAT; ++ii) {
+            const int i = ib + ii;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float x = acc[i][2 * jp][r], y = acc[i][2 * jp + 1][r];
+              row_swap(x, y);
+              v[r] = x;
+              v[4 + r] = y;
+            }
+            if (rb_row) {
+              const float* rbp = p.rowbias + ((int64_t)(mrow + i * 16) / p.rows_per_group) * p.ld_rowbias + n;
+              const float4 b0 = *(const float4*)rbp, b1 = *(const float4*)(rbp + 4);
+              v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+              v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+            }
+            if (has_res) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) v[e] += (float)res[ii].e[e];
+            }
+            char* op = outb + (size_t)(i * 16) * ldo_b + on;
+            if (p.out_f32) {
+              *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
+              *(float4*)(op + 16) = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+              U4H8 t;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) t.e[e] = (f16)v[e];
+              *(u32x4*)op = t.u;
+            }
+          }
+        }
+      }
+      if (NB & 1) {
+        const int n = n0 + wn * WTN + (NB - 1) * 16 + fq * 4;
+        const uint32_t rn = rrow + (uint32_t)n * 2u, on = orow + (uint32_t)n * esz;
+        union H4 { u32x2 u; f16 e[4]; };
+#pragma unroll
+        for (int ib = 0; ib < FM; ib += RBAT) {
+          H4 res[RBAT];
+          if (has_res) {
+#pragma unroll
+            for (int i = 0; i < RBAT; ++i) res[i].u = *(const u32x2*)(resb + (size_t)((ib + i) * 16) * ldr_b + rn);
+          }
+#pragma unroll
+          for (int ii = 0; ii < RBAT; ++ii) {
+            const int i = ib + ii;
+            float v[4] = {acc[i][NB - 1][0], acc[i][NB - 1][1], acc[i][NB - 1][2], acc[i][NB - 1][3]};
+            if (rb_row) {
+              const float4 b = *(const float4*)(p.rowbias + ((int64_t)(mrow + i * 16) / p.rows_per_group) * p.ld_rowbias + n);
+              v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+            }
+            if (has_res) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += (float)res[ii].e[e];
+            }
+            char* op = outb + (size_t)(i * 16) * ldo_b + on;
+            if (p.out_f32) {
+              *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+              H4 t;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) t.e[e] = (f16)v[e];
+              *(u32x2*)op = t.u;
+            }
+          }
+        }
       }
     }
   }

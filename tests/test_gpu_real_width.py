@@ -1,0 +1,136 @@
+"""End-to-end parity of the public pipeline at the REAL SD-1.5 / sd-vae-ft-mse widths (head dims 40 / 80 / 160) on
+BASELINE.json's own configurations, against the CPU oracle (oracle/ref_torch.py, fp32) on the GPU box's host cores —
+the north star's criterion: PSNR >= 40 dB on the decoded frames for identical weights, latents and inputs
+(reference loop: src/pipelines/pipeline_pose2vid_long.py:458-559).
+
+  C1 in full          256x256, L=4, 10 DDIM steps, CFG 3.5                       (BASELINE configs[0])
+  windowed            256x256, L=24 -> two 16-frame windows, 2 steps              (the C4 mechanism at real width)
+  C2, reduced steps   512x512, L=16, 2 steps + ReferenceNet + 16 VAE frames      (BASELINE configs[1]; `slow`)
+  graph reuse         clip A, a different clip B (other image / poses / latents / resolution), clip A again through the
+                      SAME pipeline object with the captured hipGraph active: every clip matches the oracle and A is
+                      bit-identical before and after B (in-place bank / attn2 refresh, runner cache)
+"""
+import time
+
+import pytest
+import torch
+
+from util import build_hip_models_cached, clip_encoder_for, oracle_threads, psnr
+
+pytestmark = pytest.mark.gpu
+PSNR_BAR = 40.0
+
+
+def _pipe(small, long=True):
+    from aniportrait_amd import configs as C
+    from aniportrait_amd.scheduling_ddim import DDIMScheduler
+    from src.pipelines.pipeline_pose2vid import Pose2VideoPipeline as ShortPipe
+    from src.pipelines.pipeline_pose2vid_long import Pose2VideoPipeline as LongPipe
+    m, sds = build_hip_models_cached(small)
+    pipe = (LongPipe if long else ShortPipe)(
+        vae=m["vae"], image_encoder=clip_encoder_for(small), reference_unet=m["reference_unet"],
+        denoising_unet=m["denoising_unet"], pose_guider=m["pose_guider"], scheduler=DDIMScheduler(**C.DDIM_V2))
+    pipe.set_progress_bar_config(disable=True)
+    return pipe, sds
+
+
+@pytest.fixture(scope="module")
+def real_pipe():
+    return _pipe(False)
+
+
+def _clip(H, W, L, seed):
+    from aniportrait_amd.synthetic import synth_latents, synth_pose_frames, synth_ref_image
+    return dict(H=H, W=W, L=L, ref_image=synth_ref_image(H, W, 1 + seed), poses=list(synth_pose_frames(L, H, W, 1234 + 100 * seed)),
+                ref_pose=synth_pose_frames(1, H, W, 999)[0], latents=synth_latents(L, H // 8, W // 8, 42 + seed))
+
+
+def _run(pipe, c, steps, cfg=3.5, **kw):
+    return pipe(c["ref_image"], list(c["poses"]), c["ref_pose"], c["W"], c["H"], c["L"], steps, cfg,
+                latents=c["latents"], **kw).videos
+
+
+def _oracle(pipe, sds, small, c, steps, cfg=3.5, **kw):
+    from aniportrait_amd import configs as C
+    from oracle import ref_torch as O
+    n = oracle_threads()
+    clip = pipe._clip_embeds(c["ref_image"], torch.device("cpu")).float()
+    cfgs = {"unet": C.unet3d_kwargs(small), "vae": C.SD_VAE_SMALL if small else C.SD_VAE_FT_MSE}
+    t0 = time.time()
+    ref = O.pose2vid(sds, cfgs, clip, c["ref_image"], list(c["poses"]), c["ref_pose"], c["W"], c["H"], c["L"], steps, cfg,
+                     c["latents"], long=True, **kw)
+    return ref, time.time() - t0, n
+
+
+@torch.no_grad()
+def test_c1_in_full_and_graph_reuse_at_real_width(real_pipe):
+    """BASELINE configs[0] in full; then another clip shape through the same pipeline; then C1 again: bit-identical"""
+    pipe, sds = real_pipe
+    a = _clip(256, 256, 4, 0)
+    vid = _run(pipe, a, 10)
+    ref, secs, n = _oracle(pipe, sds, False, a, 10)
+    p = psnr(vid, ref)
+    print(f"C1 256x256 L=4 10 steps CFG 3.5, real width: PSNR vs CPU oracle = {p:.2f} dB (oracle {secs:.0f} s on {n} threads)")
+    assert vid.shape == ref.shape == (1, 3, 4, 256, 256) and p >= PSNR_BAR
+    # a different clip in between: other image / poses / latents AND another latent size (new bank shapes, new runner)
+    b = _clip(128, 192, 4, 7)
+    vb = _run(pipe, b, 2)
+    rb, _, _ = _oracle(pipe, sds, False, b, 2)
+    pb = psnr(vb, rb)
+    print(f"clip B 128x192 L=4 2 steps: PSNR = {pb:.2f} dB")
+    assert pb >= PSNR_BAR
+    again = _run(pipe, a, 10)
+    assert torch.equal(again, vid), f"clip A differs after clip B went through the cached graphs: {psnr(again, vid):.1f} dB"
+
+
+@torch.no_grad()
+def test_windowed_long_clip_at_real_width(real_pipe):
+    """two overlapping 16-frame context windows per step (the C4 mechanism) at real width"""
+    pipe, sds = real_pipe
+    c = _clip(256, 256, 24, 1)
+    vid = _run(pipe, c, 2)
+    ref, secs, n = _oracle(pipe, sds, False, c, 2)
+    p = psnr(vid, ref)
+    print(f"windowed 256x256 L=24 (2 windows) 2 steps: PSNR = {p:.2f} dB (oracle {secs:.0f} s on {n} threads)")
+    assert p >= PSNR_BAR
+
+
+@pytest.mark.slow
+@torch.no_grad()
+def test_c2_reduced_steps_at_real_width(real_pipe):
+    """BASELINE configs[1] geometry (512x512, L=16, CFG 3.5) at 2 DDIM steps: ReferenceNet + 2 UNet3D calls on the
+    32-frame CFG batch + 16 VAE frames, everything at the sizes the bench runs"""
+    pipe, sds = real_pipe
+    c = _clip(512, 512, 16, 2)
+    vid = _run(pipe, c, 2)
+    ref, secs, n = _oracle(pipe, sds, False, c, 2)
+    p = psnr(vid, ref)
+    print(f"C2 512x512 L=16 2 steps: PSNR = {p:.2f} dB (oracle {secs:.0f} s on {n} threads)")
+    assert p >= PSNR_BAR
+
+
+@torch.no_grad()
+def test_two_different_clips_through_one_graph_small_width():
+    """small width (cheap oracle): A -> B (same shapes, different content) -> A' (other resolution) -> A, all through
+    one pipeline object with the hipGraph active; every clip vs the oracle, A bit-identical each time"""
+    pipe, sds = _pipe(True)
+    a, b, c = _clip(128, 128, 4, 0), _clip(128, 128, 4, 5), _clip(192, 128, 4, 6)
+    outs = []
+    for clip_ in (a, b, c, a, b):
+        outs.append(_run(pipe, clip_, 3))
+    for clip_, got in zip((a, b, c), outs[:3]):
+        ref, _, _ = _oracle(pipe, sds, True, clip_, 3)
+        p = psnr(got, ref)
+        print(f"small-width clip {clip_['H']}x{clip_['W']}: PSNR = {p:.2f} dB")
+        assert p >= PSNR_BAR
+    assert torch.equal(outs[3], outs[0]) and torch.equal(outs[4], outs[1])
+    assert not torch.equal(outs[0], outs[1])
+    # no-CFG clip in between (batch 1: other attn2 / bank buffers), then A again
+    _run(pipe, a, 2, cfg=1.0)
+    assert torch.equal(_run(pipe, a, 3), outs[0])
+    # the runner cache is bounded
+    pipe.max_cached_graphs = 1
+    _run(pipe, c, 2)
+    assert len(pipe._get_runners()) == 1
+    pipe.drop_cached_graphs()
+    assert len(pipe._get_runners()) == 0

@@ -76,3 +76,38 @@ def psnr(a, b, peak=1.0):
     import math
     mse = torch.mean((a.double().cpu() - b.double().cpu()) ** 2).item()
     return float("inf") if mse == 0 else 10.0 * math.log10(peak * peak / mse)
+
+
+_MODEL_CACHE = {}
+
+
+def build_hip_models_cached(small, device="cuda"):
+    """`build_hip_models` once per test session and width (the real-width state-dicts take a minute to synthesise)"""
+    key = (bool(small), device)
+    if key not in _MODEL_CACHE:
+        _MODEL_CACHE[key] = build_hip_models(small, device=device)
+    return _MODEL_CACHE[key]
+
+
+def clip_encoder_for(small, device="cuda"):
+    """tiny CLIP vision tower (fp32, name-hash weights) projecting to the UNet's cross_attention_dim: the CLIP image
+    encoder is outside the HIP scope (SURVEY.md §2.1 #12) and only its (1, D) output enters the path"""
+    if small:
+        return small_clip_encoder(device)
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+
+    from aniportrait_amd import configs as C
+    from aniportrait_amd.synthetic import fill_module_
+    enc = CLIPVisionModelWithProjection(CLIPVisionConfig(**dict(C.CLIP_SMALL, projection_dim=768)))
+    return fill_module_(enc, 0, "image_encoder768.").eval().to(device)
+
+
+def oracle_threads():
+    """bound the CPU oracle's thread pool: hundreds of schedulable cores on the GPU box oversubscribe small GEMMs"""
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 8
+    torch.set_num_threads(max(1, min(64, n)))
+    return torch.get_num_threads()

@@ -30,21 +30,37 @@ def r16(*shape, scale=1.0):
     return (torch.randn(shape, device=DEV) * scale).half()
 
 
-def bench_gemm(M, N, K, tag):
-    A, W = r16(M, K), r16(N, K, scale=K ** -0.5)
-    b = torch.randn(N, device=DEV)
-    t = timeit(lambda: ops.gemm(A, W, b))
-    print(json.dumps(dict(kernel="gemm", tag=tag, M=M, N=N, K=K, ms=t * 1e3, tflops=2 * M * N * K / t / 1e12)), flush=True)
+def bench_gemm(M, N, K, tag, res=False, rb=False, geglu=False, a2=0, trans=False):
+    """the epilogue variants of the path: bias / +residual / +row-group bias (time embedding, collapsed attn2) /
+    GEGLU / two-source A (fused skip concat) / transposed out (V^T projection)"""
+    A, W = r16(M, K - a2), r16(N, K, scale=K ** -0.5)
+    A2 = r16(M, a2) if a2 else None
+    b = None if trans else torch.randn(N, device=DEV)
+    if geglu:
+        W, b = ops.pack_geglu(W, b)
+    n_out = N // 2 if geglu else N
+    R = r16(M, n_out) if res else None
+    RB = torch.randn((M // 4096 if M >= 4096 else 1, n_out), device=DEV) if rb else None
+    t = timeit(lambda: ops.gemm(A, W, b, A2=A2, residual=R, rowbias=RB, rows_per_group=4096 if M >= 4096 else M,
+                                act=1 if geglu else 0, trans_out=trans))
+    by = 2 * (A.numel() + (A2.numel() if a2 else 0) + W.numel() + M * n_out * (2 if res else 1))
+    print(json.dumps(dict(kernel="gemm", tag=tag, M=M, N=N, K=K, res=res, rb=rb, geglu=geglu, a2=a2, trans=trans,
+                          us=t * 1e6, tflops=2 * M * N * K / t / 1e12, gbps=by / t / 1e9)), flush=True)
 
 
-def bench_conv(N, H, Cin, Cout, tag, up=False, stride=1):
+def bench_conv(N, H, Cin, Cout, tag, up=False, stride=1, res=False, rb=False, pad=1, pad_hi=None):
     x = r16(N, H, H, Cin)
     w = ops.pack_conv3x3(r16(Cout, Cin, 3, 3, scale=(9 * Cin) ** -0.5))
     b = torch.randn(Cout, device=DEV)
-    t = timeit(lambda: ops.conv3x3(x, w, b, stride=stride, upsample=up))
-    Ho = (2 * H if up else H) // stride
-    fl = 2 * N * Ho * Ho * Cout * 9 * Cin
-    print(json.dumps(dict(kernel="conv3x3", tag=tag, N=N, H=H, Cin=Cin, Cout=Cout, ms=t * 1e3, tflops=fl / t / 1e12)), flush=True)
+    y = ops.conv3x3(x, w, b, stride=stride, upsample=up, pad=pad, pad_hi=pad_hi)
+    R = torch.randn_like(y) if res else None
+    RB = torch.randn((2, Cout), device=DEV) if rb else None
+    rpg = (y.shape[0] * y.shape[1] * y.shape[2]) // 2
+    t = timeit(lambda: ops.conv3x3(x, w, b, stride=stride, upsample=up, pad=pad, pad_hi=pad_hi, residual=R, rowbias=RB,
+                                   rows_per_group=rpg))
+    fl = 2 * y.shape[0] * y.shape[1] * y.shape[2] * Cout * 9 * Cin
+    print(json.dumps(dict(kernel="conv3x3", tag=tag, N=N, H=H, Cin=Cin, Cout=Cout, res=res, rb=rb, up=up, stride=stride,
+                          us=t * 1e6, tflops=fl / t / 1e12)), flush=True)
 
 
 def bench_attn(Nf, T, heads, d, tag):
@@ -82,45 +98,70 @@ def bench_temporal(B, F, T, heads, d, tag):
 
 
 def main():
-    quick = "--quick" in sys.argv
-    print(json.dumps(dict(device=ops.device_info())), flush=True)
+    """--only gemm,conv,attn,norm   restrict the families;   env switches of the library (read once per process) make
+    one invocation = one kernel variant: ANIP_GEMM2_DBG=8 (round-1 epilogue), ANIP_GEMM2_CFG=1|2 (never / always the
+    wide tiles), ANIP_ATTN_QH=1|2 (query groups per wave)."""
+    import os
+    only = None
+    for a in sys.argv[1:]:
+        if a.startswith("--only"):
+            only = set(a.split("=", 1)[1].split(","))
+    want = lambda k: only is None or k in only  # noqa: E731
+    print(json.dumps(dict(device=ops.device_info(), env={k: v for k, v in os.environ.items() if k.startswith("ANIP_")})),
+          flush=True)
     NF = 32
-    if "--attn" in sys.argv:
+    if want("gemm"):
+        # the Linear / 1x1 layers of one UNet3D call at C2 (shape, epilogue) — launches per call in the tag
+        bench_gemm(NF * 4096, 320, 320, "64^2 out-proj/proj_out x4", res=True)
+        bench_gemm(NF * 4096, 320, 320, "64^2 attn1 out-proj +attn2 x1", res=True, rb=True)
+        bench_gemm(NF * 4096, 320, 320, "64^2 proj_in x2")
+        bench_gemm(NF * 4096, 320, 320, "64^2 to_v^T x1", trans=True)
+        bench_gemm(NF * 4096, 640, 320, "64^2 q|k x1")
+        bench_gemm(NF * 4096, 960, 320, "64^2 temporal qkv x2")
+        bench_gemm(NF * 4096, 2560, 320, "64^2 ff-in geglu x2", geglu=True)
+        bench_gemm(NF * 4096, 320, 1280, "64^2 ff-out x2", res=True)
+        bench_gemm(NF * 4096, 320, 640, "64^2 shortcut 640->320 (concat)", a2=320)
+        bench_gemm(NF * 1024, 640, 640, "32^2 out-proj x4", res=True)
+        bench_gemm(NF * 1024, 1920, 640, "32^2 temporal qkv x2")
+        bench_gemm(NF * 1024, 5120, 640, "32^2 ff-in geglu x2", geglu=True)
+        bench_gemm(NF * 1024, 640, 2560, "32^2 ff-out x2", res=True)
+        bench_gemm(NF * 256, 1280, 1280, "16^2 out-proj x4", res=True)
+        bench_gemm(NF * 256, 3840, 1280, "16^2 temporal qkv x2")
+        bench_gemm(NF * 256, 10240, 1280, "16^2 ff-in geglu x2", geglu=True)
+        bench_gemm(NF * 256, 1280, 5120, "16^2 ff-out x2", res=True)
+        bench_gemm(NF * 64, 1280, 1280, "8^2 out-proj", res=True)
+        bench_gemm(NF * 64, 1280, 2560, "8^2 shortcut 2560->1280 (concat)", a2=1280)
+        bench_gemm(NF * 64, 10240, 1280, "8^2 ff-in geglu", geglu=True)
+        bench_gemm(NF * 64, 1280, 5120, "8^2 ff-out", res=True)
+        bench_gemm(8192, 8192, 8192, "square 8k")
+    if want("conv"):
+        bench_conv(NF, 64, 320, 320, "res 64^2 320 conv2", res=True)
+        bench_conv(NF, 64, 320, 320, "res 64^2 320 conv1", rb=True)
+        bench_conv(NF, 64, 640, 320, "res 64^2 640->320 conv1", rb=True)
+        bench_conv(NF, 32, 640, 640, "res 32^2 640 conv2", res=True)
+        bench_conv(NF, 16, 1280, 1280, "res 16^2 1280 conv2", res=True)
+        bench_conv(NF, 8, 1280, 1280, "res 8^2 1280 conv2", res=True)
+        bench_conv(NF, 8, 2560, 1280, "res 8^2 2560->1280 conv1", rb=True)
+        bench_conv(NF, 32, 640, 640, "up 32->64", up=True)
+        bench_conv(16, 256, 256, 256, "vae 256^2 256", res=True)
+        bench_conv(16, 512, 128, 128, "vae 512^2 128", res=True)
+        bench_conv(1, 256, 256, 256, "vae-enc 256^2 s2 pad(0,1)", stride=2, pad=0, pad_hi=1)
+    if want("attn"):
         bench_attn(NF, 4096, 8, 40, "64^2 d40")
         bench_attn(NF, 1024, 8, 80, "32^2 d80")
         bench_attn(NF, 256, 8, 160, "16^2 d160")
         bench_attn(NF, 64, 8, 160, "8^2 d160")
-        return
-    # linear layers of the 64^2 / 32^2 / 16^2 levels
-    bench_gemm(NF * 4096, 640, 320, "qk-proj 64^2")
-    bench_gemm(NF * 4096, 320, 320, "out-proj 64^2")
-    bench_gemm(NF * 4096, 2560, 320, "ff-in 64^2 (as plain)")
-    bench_gemm(NF * 4096, 320, 1280, "ff-out 64^2")
-    bench_gemm(NF * 1024, 640, 2560, "ff-out 32^2")
-    bench_gemm(NF * 256, 1280, 5120, "ff-out 16^2")
-    bench_gemm(8192, 8192, 8192, "square 8k")
-    if not quick:
-        bench_gemm(4096, 4096, 4096, "square 4k")
-        bench_gemm(NF * 64, 1280, 1280, "proj 8^2")
-    bench_conv(NF, 64, 320, 320, "res 64^2 320")
-    bench_conv(NF, 32, 640, 640, "res 32^2 640")
-    bench_conv(NF, 16, 1280, 1280, "res 16^2 1280")
-    bench_conv(NF, 8, 2560, 1280, "res 8^2 2560->1280")
-    if not quick:
-        bench_conv(NF, 64, 960, 320, "res 64^2 960->320")
-        bench_conv(16, 256, 256, 256, "vae 256^2 256")
-        bench_conv(16, 512, 128, 128, "vae 512^2 128")
-        bench_conv(NF, 32, 640, 640, "up 32->64", up=True)
-    bench_attn(NF, 4096, 8, 40, "64^2 d40")
-    bench_attn(NF, 1024, 8, 80, "32^2 d80")
-    bench_attn(NF, 256, 8, 160, "16^2 d160")
-    bench_gn(NF, 4096, 320, "64^2 C320")
-    bench_gn(NF, 4096, 960, "64^2 C960")
-    bench_gn(16, 262144, 128, "vae 512^2 C128")
-    bench_ln(NF * 4096, 320, "64^2 C320")
-    bench_ln(NF * 256, 1280, "16^2 C1280")
-    bench_temporal(2, 16, 4096, 8, 40, "64^2 d40")
-    bench_temporal(2, 16, 256, 8, 160, "16^2 d160")
+    if want("norm"):
+        bench_gn(NF, 4096, 320, "64^2 C320")
+        bench_gn(NF, 4096, 960, "64^2 C960")
+        bench_gn(NF, 1024, 640, "32^2 C640")
+        bench_gn(16, 262144, 128, "vae 512^2 C128")
+        bench_ln(NF * 4096, 320, "64^2 C320")
+        bench_ln(NF * 1024, 640, "32^2 C640")
+        bench_ln(NF * 256, 1280, "16^2 C1280")
+        bench_temporal(2, 16, 4096, 8, 40, "64^2 d40")
+        bench_temporal(2, 16, 1024, 8, 80, "32^2 d80")
+        bench_temporal(2, 16, 256, 8, 160, "16^2 d160")
 
 
 if __name__ == "__main__":
