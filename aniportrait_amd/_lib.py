@@ -9,7 +9,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libaniportrait_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -72,6 +72,7 @@ SIGNATURES = {
     "anip_nhwc_to_ncfhw": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_float, c_float, c_int,
                                    c_void_p]),
     "anip_u8_to_f16": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p]),
+    "anip_f16_to_u8": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p]),
     "anip_profile_enable": (c_int, [c_int]),
     "anip_profile_collect": (c_int, [c_int, C.POINTER(c_int64), C.POINTER(C.c_double)]),
     "anip_profile_collect_records": (c_int, [c_int, C.POINTER(c_int64), C.POINTER(C.c_double), c_int64,

@@ -217,6 +217,34 @@ __global__ __launch_bounds__(NT) void u8_to_f16_kernel(const uint8_t* __restrict
     for (int64_t i = (nv << 3) + threadIdx.x; i < n; i += NT) dst[i] = (f16)(scale * (float)src[i] + shift);
 }
 
+// dst[i] = (uint8) trunc(255 * fp16(clamp(scale * src[i] + shift, 0, 1))): decoded VAE frames (channels-last, already
+// the (L,H,W,3) image layout) -> display bytes.  The value is rounded to fp16 first because that is what the
+// reference's fp16 pipeline hands to save_videos_grid, which then does (x * 255).astype(uint8) in fp32
+// (src/pipelines/pipeline_pose2vid_long.py:123-125, src/utils/util.py:97-98).
+__global__ __launch_bounds__(NT) void f16_to_u8_kernel(const f16* __restrict__ src, uint8_t* __restrict__ dst, int64_t n,
+                                                      float scale, float shift) {
+  const int64_t stride = (int64_t)gridDim.x * NT;
+  const int64_t nv = n >> 3;
+  for (int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x; i < nv; i += stride) {
+    U4H8 x;
+    x.u = ((const u32x4*)src)[i];
+    unsigned int lo = 0, hi = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float c = fminf(fmaxf((float)x.e[e] * scale + shift, 0.f), 1.f);
+      const unsigned int b = (unsigned int)((float)(f16)c * 255.0f);
+      if (e < 4) lo |= b << (8 * e);
+      else hi |= b << (8 * (e - 4));
+    }
+    ((u32x2*)dst)[i] = u32x2{lo, hi};
+  }
+  if (blockIdx.x == 0)
+    for (int64_t i = (nv << 3) + threadIdx.x; i < n; i += NT) {
+      const float c = fminf(fmaxf((float)src[i] * scale + shift, 0.f), 1.f);
+      dst[i] = (uint8_t)((float)(f16)c * 255.0f);
+    }
+}
+
 inline unsigned grid_for(int64_t work) {
   int64_t b = (work + NT - 1) / NT;
   if (b < 1) b = 1;
@@ -342,5 +370,17 @@ extern "C" int anip_u8_to_f16(const void* src, void* dst, int64_t n, float scale
                        (f16*)dst, n, scale, shift);
   }
   ANIP_LAUNCH_CHECK("anip_u8_to_f16");
+  return 0;
+}
+
+extern "C" int anip_f16_to_u8(const void* src, void* dst, int64_t n, float scale, float shift, void* stream) {
+  ANIP_REQUIRE(src && dst && n > 0, "anip_f16_to_u8: bad arguments");
+  ANIP_REQUIRE(((uintptr_t)src & 15) == 0 && ((uintptr_t)dst & 7) == 0, "anip_f16_to_u8: src must be 16-B, dst 8-B aligned");
+  {
+    AnipProfScope prof_(ANIP_K_ELEMENTWISE, stream);
+    hipLaunchKernelGGL(f16_to_u8_kernel, dim3(grid_for(n / 8 + 1)), dim3(NT), 0, (hipStream_t)stream, (const f16*)src,
+                       (uint8_t*)dst, n, scale, shift);
+  }
+  ANIP_LAUNCH_CHECK("anip_f16_to_u8");
   return 0;
 }

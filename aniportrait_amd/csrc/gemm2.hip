@@ -31,6 +31,11 @@ namespace {
 
 constexpr uint32_t OOB = 0xFFFFFFF0u;
 
+// -DANIP_GEMM2_EXPERIMENTS compiles the main-loop ablation switches in (ANIP_GEMM2_DBG bit 2: no global->LDS traffic,
+// bit 4: no MFMAs).  They are runtime branches INSIDE the K loop — a uniform branch per 16-row fragment group, which
+// pins every A-fragment ds_read directly in front of its MFMAs with an lgkmcnt(0) between them — so production builds
+// leave them out; bits 1 (no epilogue) and 8 (round-1 epilogue) sit outside the loop and stay available.
+
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 // bank swizzle of the 16-B chunk index inside an LDS row (applied on the DMA SOURCE address and on the
@@ -85,6 +90,11 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
     swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int bm = swz / nbn, bn = swz % nbn, m0 = bm * BM2, n0 = bn * BN;
+
+  // experiment (ANIP_GEMM2_DBG >> 8 = k): the blocks of every second dispatch round sleep k x 8128 cycles before they
+  // start, which puts the two blocks resident on a CU out of phase (one in its main loop while the other stores)
+  if ((dbg >> 8) != 0 && ((blockIdx.x >> 8) & 1))
+    for (int i = 0; i < (dbg >> 8); ++i) __builtin_amdgcn_s_sleep(127);
 
   const f16* Ap = (const f16*)p.A;
   const f16* Wp = (const f16*)p.W;
@@ -141,7 +151,9 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
   const int my_b = (NB_TOT - wave + NW - 1) / NW;  // B DMA instructions this wave issues (wave-uniform)
 
   auto issue = [&](int kt, int stage) {
+#ifdef ANIP_GEMM2_EXPERIMENTS
     if (dbg & 2) return;   // experiment: no global->LDS traffic
+#endif
     char* sa = smem + stage * STAGE;
     char* sb = sa + A_BYTES;
     const int k0 = kt * BKT;
@@ -260,7 +272,9 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_setprio(1);
+#ifdef ANIP_GEMM2_EXPERIMENTS
       if (!(dbg & 4))
+#endif
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -298,7 +312,9 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
           const f16x8 af = *(const f16x8*)(sa + a_row_off + i * 16 * RB + koff[kh]);
+#ifdef ANIP_GEMM2_EXPERIMENTS
           if (!(dbg & 4))      // experiment: no MFMAs
+#endif
 #pragma unroll
             for (int j = 0; j < NB; ++j)
               acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0)

@@ -41,9 +41,26 @@ def shard_balanced(costs, world_size):
     return [sorted(x) for x in out]
 
 
+def window_sum_buffers(S, L, HWC, device):
+    """(flat, acc, counter): the per-step window sums of one clip as views of ONE persistent fp32 buffer, so the
+    per-step exchange is a single in-place all-reduce of `flat` — no packing copy before it and none after."""
+    n = S * L * HWC
+    flat = torch.empty((n + L,), dtype=torch.float32, device=device)
+    return flat, flat[:n].view(S, L, HWC), flat[n:]
+
+
+def allreduce_flat(flat, group=None):
+    """in-place sum over ranks of the buffer made by `window_sum_buffers` (each rank ran its own windows)"""
+    rank, ws = world(group)
+    if ws > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return flat
+
+
 def allreduce_window_sums(acc, counter, group=None):
-    """Sum the per-frame accumulators of one DDIM step over ranks (each rank ran its own windows).
-    One flat message: acc and counter are packed together."""
+    """Sum the per-frame accumulators of one DDIM step over ranks (each rank ran its own windows), for callers whose
+    acc / counter are separate tensors: packed into one flat message (the pipeline itself uses `window_sum_buffers` +
+    `allreduce_flat`, which needs no packing)."""
     rank, ws = world(group)
     if ws == 1:
         return acc, counter
@@ -56,42 +73,45 @@ def allreduce_window_sums(acc, counter, group=None):
 
 
 def broadcast_tensors(tensors, src=0, group=None):
-    """Broadcast a list of same-dtype tensors (shapes known on every rank) as one flat buffer, in place."""
+    """Broadcast a list of same-dtype tensors (shapes known on every rank) as one flat buffer, in place.  Once per clip
+    (the 16 ReferenceNet banks, 46 MB at 512x512): one large message suits the point-to-point xGMI links better than
+    16 small ones; the packing copy is paid once per clip, not per step."""
     rank, ws = world(group)
     if ws == 1 or not tensors:
         return tensors
     flat = torch.cat([t.reshape(-1) for t in tensors])
     dist.broadcast(flat, src=src, group=group)
-    o = 0
-    for t in tensors:
-        t.copy_(flat[o:o + t.numel()].view_as(t))
-        o += t.numel()
+    if rank != src:
+        o = 0
+        for t in tensors:
+            t.copy_(flat[o:o + t.numel()].view_as(t))
+            o += t.numel()
     return tensors
 
 
-def gather_frames(local_frames, local_idx, n_frames, dst=0, group=None):
-    """local_frames (n_local, ...) holding global frame indices `local_idx`; returns the (n_frames, ...)
-    tensor on `dst` (None elsewhere).  Ranks may own different frame counts."""
+def gather_frames(local_frames, local_idx, n_frames, dst=0, group=None, owner_fn=None):
+    """local_frames (n_local, ...) holding global frame indices `local_idx`; returns the (n_frames, ...) tensor on
+    `dst` (None elsewhere).  Ranks may own different frame counts: every rank sends one buffer padded to the largest
+    share, and ONLY `dst` receives (dist.gather) — the frame indices of every rank follow from the sharding rule
+    (`owner_fn(rank) -> indices`, default round robin), so they are not communicated."""
     rank, ws = world(group)
+    dev = local_frames.device
     if ws == 1:
-        out = torch.empty((n_frames,) + tuple(local_frames.shape[1:]), dtype=local_frames.dtype,
-                          device=local_frames.device)
-        out[torch.as_tensor(local_idx, dtype=torch.long, device=local_frames.device)] = local_frames
+        out = torch.empty((n_frames,) + tuple(local_frames.shape[1:]), dtype=local_frames.dtype, device=dev)
+        out[torch.as_tensor(local_idx, dtype=torch.long, device=dev)] = local_frames
         return out
-    per = -(-n_frames // ws)
-    pad = torch.zeros((per,) + tuple(local_frames.shape[1:]), dtype=local_frames.dtype, device=local_frames.device)
+    owner_fn = owner_fn or (lambda r: shard_round_robin(n_frames, r, ws))
+    assert list(local_idx) == list(owner_fn(rank)), "gather_frames: local_idx does not follow the sharding rule"
+    per = max(len(owner_fn(r)) for r in range(ws))
+    pad = torch.zeros((per,) + tuple(local_frames.shape[1:]), dtype=local_frames.dtype, device=dev)
     pad[: local_frames.shape[0]] = local_frames
-    idx = torch.full((per,), -1, dtype=torch.long, device=local_frames.device)
-    idx[: len(local_idx)] = torch.as_tensor(local_idx, dtype=torch.long, device=local_frames.device)
-    bufs = [torch.empty_like(pad) for _ in range(ws)]
-    ibufs = [torch.empty_like(idx) for _ in range(ws)]
-    dist.all_gather(bufs, pad, group=group)
-    dist.all_gather(ibufs, idx, group=group)
+    bufs = [torch.empty_like(pad) for _ in range(ws)] if rank == dst else None
+    dist.gather(pad, bufs, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
     if rank != dst:
         return None
-    out = torch.empty((n_frames,) + tuple(local_frames.shape[1:]), dtype=local_frames.dtype,
-                      device=local_frames.device)
-    for b, i in zip(bufs, ibufs):
-        keep = i >= 0
-        out[i[keep]] = b[keep]
+    out = torch.empty((n_frames,) + tuple(local_frames.shape[1:]), dtype=local_frames.dtype, device=dev)
+    for r, b in enumerate(bufs):
+        idx = owner_fn(r)
+        if idx:
+            out[torch.as_tensor(idx, dtype=torch.long, device=dev)] = b[: len(idx)]
     return out

@@ -13,7 +13,12 @@ Extra keyword arguments (all optional, reference callers never pass them):
   latents=         (1, 4, L, h, w) initial noise, injected instead of `prepare_latents` (parity tests);
   dp_group=        torch.distributed process group: shard the context windows of this clip over its ranks
                    (aniportrait_amd.distributed); every rank must make the same call;
-  decode_chunk=    frames per VAE decode batch (default 16).
+  decode_chunk=    frames per VAE decode batch (default 16);
+  output_type=     "tensor" / "numpy" as in the reference (fp32 (1,3,L,H,W) in [0,1] on the host), or "uint8":
+                   display bytes (L,H,W,3) converted on the device (what save_videos_grid computes per frame on the host,
+                   src/utils/util.py:97-98), a quarter of the D2H bytes;
+  async_output=    True: `.videos` is a `PendingVideo`; the D2H copy runs on a side stream into pinned memory and
+                   `.result()` waits for it — lets a caller start the next clip while the frames drain.
 """
 import inspect
 import math
@@ -110,6 +115,27 @@ class _DenoiseRunner:
             self.graph = g
         self.graph.replay()
         return self.pred
+
+
+class PendingVideo:
+    """Frames on their way to the host: device tensor -> pinned buffer on the pipeline's copy stream.  `.result()`
+    waits for the copy and returns what the synchronous path returns (the reference's `.cpu().float()` order,
+    src/pipelines/pipeline_pose2vid_long.py:125: fp16 over the bus, fp32 on the host)."""
+
+    def __init__(self, host, event, finish, keep):
+        self._host, self._event, self._finish, self._keep = host, event, finish, keep
+        self._out = None
+
+    def done(self):
+        return self._event is None or self._event.query()
+
+    def result(self):
+        if self._out is None:
+            if self._event is not None:
+                self._event.synchronize()
+            self._out = self._finish(self._host)
+            self._keep = None
+        return self._out
 
 
 class Pose2VideoPipelineOutput(BaseOutput):
@@ -260,13 +286,17 @@ class Pose2VideoPipeline(_Base):
         z = ops.ncfhw_to_nhwc((latents.to(self.device).float() * (1 / 0.18215)).contiguous())
         return self._decode_nhwc(z, b, decode_chunk).cpu().float().numpy()
 
-    def _decode_nhwc(self, z, b, decode_chunk=16):
-        """z (b*L, h, w, 4) fp16 (already divided by the scaling factor) -> (b, 3, L, H, W) fp16 in [0,1]"""
+    def _decode_nhwc(self, z, b, decode_chunk=16, as_u8=False):
+        """z (b*L, h, w, 4) fp16 (already divided by the scaling factor) -> (b, 3, L, H, W) fp16 in [0,1], or, with
+        `as_u8`, display bytes (b*L, H, W, 3) uint8 — the decoder's channels-last output IS the image layout"""
         vae = self._vae()
         outs = []
         for s in range(0, z.shape[0], decode_chunk):
-            outs.append(vae.decode_nhwc(z[s:s + decode_chunk].contiguous()))
+            x = vae.decode_nhwc(z[s:s + decode_chunk].contiguous())
+            outs.append(ops.f16_to_u8(x, 0.5, 0.5) if as_u8 else x)
         x = torch.cat(outs, dim=0) if len(outs) > 1 else outs[0]
+        if as_u8:
+            return x
         return ops.nhwc_to_ncfhw(x, b, out_f32=False, scale=0.5, shift=0.5, clamp01=True)
 
     def interpolate_latents(self, latents, interpolation_factor, device):
@@ -323,7 +353,8 @@ class Pose2VideoPipeline(_Base):
     @torch.no_grad()
     def _run(self, ref_image, pose_images, ref_pose_image, width, height, video_length, num_inference_steps,
              guidance_scale, num_images_per_prompt, eta, generator, output_type, return_dict, callback, callback_steps,
-             windows_fn, latents=None, dp_group=None, decode_chunk=16, return_latents=False, use_graph=True):
+             windows_fn, latents=None, dp_group=None, decode_chunk=16, return_latents=False, use_graph=True,
+             async_output=False):
         device = self._execution_device
         self._require_gpu(device)
         tm = _StageTimer()
@@ -399,7 +430,8 @@ class Pose2VideoPipeline(_Base):
         tm.mark("refnet")
 
         windows = [list(c) for c in windows_fn(L, num_inference_steps)]
-        my_windows = D.shard_round_robin(len(windows), rank, ws) if ws > 1 else list(range(len(windows)))
+        # windows -> ranks by longest-processing-time over their frame counts (equal-length windows: round robin)
+        my_windows = (D.shard_balanced([len(c) for c in windows], ws)[rank] if ws > 1 else list(range(len(windows))))
         win_idx = {k: torch.tensor(windows[k], dtype=torch.int32, device=device) for k in my_windows}
         # a dilated window can wrap onto a frame twice (context_stride > 1); the reference's index assignment
         # `noise_pred[:, :, c] = noise_pred[:, :, c] + pred` then keeps the LAST occurrence and counts the frame once
@@ -418,8 +450,8 @@ class Pose2VideoPipeline(_Base):
                 pose_cache[k] = [n.repeat(S, 1, 1, 1).contiguous() if S > 1 else n for n in fea]
             return pose_cache[k]
 
-        acc = torch.empty((S, L, HWC), dtype=torch.float32, device=device)
-        counter = torch.empty((L,), dtype=torch.float32, device=device)
+        # per-step window sums: acc (S, L, HWC) and counter (L,) are views of one flat buffer (one in-place all-reduce)
+        sums_flat, acc, counter = D.window_sum_buffers(S, L, HWC, device)
         single = len(windows) == 1 and windows[0] == list(range(L))
         # Denoising UNet forwards run through a persistent _DenoiseRunner (static input buffers).  Step 0 is eager
         # (it re-projects the reference banks / attn2 vectors in place); later steps replay the runner's hipGraph,
@@ -454,8 +486,7 @@ class Pose2VideoPipeline(_Base):
 
         with self.progress_bar(total=num_inference_steps) as bar:
             for i, t in enumerate(timesteps):
-                acc.zero_()
-                counter.zero_()
+                sums_flat.zero_()
                 for k in my_windows:
                     c = windows[k]
                     x = lat16 if single else lat16[win_idx[k].long()]
@@ -469,7 +500,7 @@ class Pose2VideoPipeline(_Base):
                 if ws > 1:
                     # also for a single window: the ranks that own no window hold zeros (acc / counter = 0 / 0
                     # otherwise), and every rank needs the step's latents for its share of the VAE decode
-                    D.allreduce_window_sums(acc, counter, dp_group)
+                    D.allreduce_flat(sums_flat, dp_group)
                 sa, sb, sap, sbp = self._fused_step_coefficients(t)
                 ops.cfg_ddim_step(acc, counter, lat32, lat16, S, L, HWC, guidance_scale, sa, sb, sap, sbp)
                 bar.update()
@@ -483,25 +514,64 @@ class Pose2VideoPipeline(_Base):
         if return_latents:
             return final
         z = (lat32 * (1 / 0.18215)).half().reshape(L, h, w, C)
+        u8 = output_type == "uint8"           # anything but "tensor" / "uint8" returns numpy, as in the reference (:581-582)
         if ws > 1:
             mine = D.shard_round_robin(L, rank, ws)
             sel = torch.tensor(mine, dtype=torch.long, device=device)
-            part = self._decode_nhwc(z[sel].contiguous(), 1, decode_chunk)          # (1, 3, n_local, H, W)
-            frames = D.gather_frames(part[0].permute(1, 0, 2, 3).contiguous(), mine, L, 0, dp_group)
-            video = None if frames is None else frames.permute(1, 0, 2, 3).unsqueeze(0)
+            part = self._decode_nhwc(z[sel].contiguous(), 1, decode_chunk, u8)      # (1, 3, n_local, H, W) | (n_local, H, W, 3)
+            local = part if u8 else part[0].permute(1, 0, 2, 3).contiguous()
+            frames = D.gather_frames(local, mine, L, 0, dp_group)
+            video = None if frames is None else (frames if u8 else frames.permute(1, 0, 2, 3).unsqueeze(0))
         else:
-            video = self._decode_nhwc(z, 1, decode_chunk)
+            video = self._decode_nhwc(z, 1, decode_chunk, u8)
         if video is None:
             return None
         tm.mark("vae_decode")
-        images = video.cpu().float().numpy()
-        if output_type == "tensor":
-            images = torch.from_numpy(images)
+
+        def finish(host):
+            if output_type == "uint8":
+                return host.clone() if async_output else host
+            images = host.float().numpy()       # fp32 up-cast on the host, after the fp16 D2H (reference order)
+            return torch.from_numpy(images) if output_type == "tensor" else images
+
+        if async_output:
+            images = self._to_host_async(video, finish)
+        else:
+            images = finish(video.cpu())
         tm.mark("d2h+float")
         tm.report()
         if not return_dict:
             return images
         return Pose2VideoPipelineOutput(videos=images)
+
+    def _to_host_async(self, video, finish):
+        """device -> pinned host buffer on a side stream.  Pinned buffers are recycled per shape once the PendingVideo
+        that used them has been consumed (or dropped), so the frames of clip i can still be draining / waiting for their
+        consumer while clips i+1, i+2 ... are produced."""
+        import weakref
+        st = self.__dict__.setdefault("_d2h", {"stream": torch.cuda.Stream(device=video.device), "bufs": {}})
+        slots = st["bufs"].setdefault((tuple(video.shape), video.dtype), [])
+        slot = None
+        for sl in slots:
+            owner = sl[1]() if sl[1] is not None else None
+            if owner is None or owner._out is not None:
+                slot = sl
+                break
+        if slot is None:
+            slot = [torch.empty(video.shape, dtype=video.dtype, pin_memory=True), None]
+            slots.append(slot)
+        host = slot[0]
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(video.device))
+        with torch.cuda.stream(st["stream"]):
+            st["stream"].wait_event(ready)
+            host.copy_(video, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record(st["stream"])
+        video.record_stream(st["stream"])
+        pending = PendingVideo(host, done, finish, video)
+        slot[1] = weakref.ref(pending)
+        return pending
 
     def _broadcast_banks(self, writer, S, h, w, group, device):
         """rank 0 holds the 16 banks; other ranks allocate same-shaped tensors; one flat RCCL broadcast."""

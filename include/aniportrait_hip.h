@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ANIP_ABI_VERSION 7
+#define ANIP_ABI_VERSION 8
 
 int anip_version(void);
 const char* anip_last_error(void);
@@ -174,6 +174,11 @@ int anip_nhwc_to_ncfhw(const void* src, void* dst, int dst_f32, int B, int C, in
  * renderings (src/pipelines/pipeline_pose2vid_long.py:445-452: values 2 v - 1 in [-1, 509], no /255), done on
  * the device on the uploaded bytes; (L,H,W,3) uint8 is already the channels-last frame batch. */
 int anip_u8_to_f16(const void* src, void* dst, int64_t n, float scale, float shift, void* stream);
+/* dst[i] = (uint8) trunc(255 * fp16(clamp(scale * src[i] + shift, 0, 1))), src fp16: decoded frames (channels-last =
+ * the (L,H,W,3) image layout) -> display bytes on the device; replaces the host-side `(x / 2 + 0.5).clamp(0, 1)` ...
+ * `(x * 255).numpy().astype(np.uint8)` of src/pipelines/pipeline_pose2vid_long.py:123-125 + src/utils/util.py:97-98
+ * (same values: the intermediate is rounded to fp16 as in the reference's fp16 run) */
+int anip_f16_to_u8(const void* src, void* dst, int64_t n, float scale, float shift, void* stream);
 
 /* ---- per-kernel timing with HIP events (bench.py's roofline leg) -------------------------------------
  * When enabled, every entry point brackets each kernel launch with hipEventRecord on the launch stream.

@@ -227,9 +227,13 @@ def u8_to_f16(src, scale=1.0, shift=0.0):
     return (src.float() * scale + shift).to(F16)
 
 
+def f16_to_u8(src, scale=1.0, shift=0.0):
+    return ((src.float() * scale + shift).clamp(0, 1).to(F16).float() * 255.0).to(torch.uint8)
+
+
 _EMULATED = ("groupnorm", "layernorm", "gemm", "ffn_geglu", "conv3x3", "conv_small", "conv_direct", "batchnorm", "ref_attention",
              "temporal_attention", "softmax_rows", "linear_small", "add", "window_accumulate", "cfg_ddim_step",
-             "ncfhw_to_nhwc", "nhwc_to_ncfhw", "u8_to_f16")
+             "ncfhw_to_nhwc", "nhwc_to_ncfhw", "u8_to_f16", "f16_to_u8")
 
 
 def install(monkeypatch):

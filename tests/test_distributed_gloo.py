@@ -42,6 +42,14 @@ def _worker(rank, world, port, q):
         acc, cnt = accumulate(mine)
         D.allreduce_window_sums(acc, cnt)
         ok1 = torch.allclose(acc, full_acc, atol=1e-5) and torch.equal(cnt, full_cnt)
+        # the pipeline's form: acc / counter as views of one persistent flat buffer, one in-place all-reduce
+        flat, acc2, cnt2 = D.window_sum_buffers(S, L, HWC, "cpu")
+        for _ in range(2):                       # reused across steps
+            flat.zero_()
+            a_, c_ = accumulate(mine)
+            acc2.copy_(a_); cnt2.copy_(c_)
+            D.allreduce_flat(flat)
+            ok1 = ok1 and torch.allclose(acc2, full_acc, atol=1e-5) and torch.equal(cnt2, full_cnt)
 
         banks = [torch.full((2, 5, 3), float(i + 1)).half() if rank == 0 else torch.zeros(2, 5, 3).half()
                  for i in range(4)]

@@ -1,0 +1,64 @@
+"""The RCCL form of tests/test_distributed_gloo.py's collective checks: 2 ranks, backend "nccl" (= RCCL over xGMI on
+ROCm), one process per GPU.  Needs two GPUs — skipped on the 1-GPU boxes the per-round GPU tests run on; the N > 1
+logic itself is covered on CPU by the gloo tests."""
+import os
+import socket
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        from aniportrait_amd import distributed as D
+        S, L, HWC = 2, 40, 64
+        flat, acc, cnt = D.window_sum_buffers(S, L, HWC, dev)
+        flat.zero_()
+        acc[:, rank::world] = float(rank + 1)
+        cnt[rank::world] = 1.0
+        D.allreduce_flat(flat)
+        ok1 = bool((acc[:, 0::2] == 1).all() and (acc[:, 1::2] == 2).all() and (cnt == 1).all())
+        banks = [torch.full((2, 5, 3), float(i + 1), device=dev).half() if rank == 0 else torch.zeros(2, 5, 3, device=dev).half()
+                 for i in range(4)]
+        D.broadcast_tensors(banks, 0)
+        ok2 = all(bool((b == float(i + 1)).all()) for i, b in enumerate(banks))
+        idx = D.shard_round_robin(7, rank, world)
+        local = torch.stack([torch.full((3, 2), float(i), device=dev) for i in idx])
+        out = D.gather_frames(local, idx, 7, 0)
+        ok3 = (out is None) if rank != 0 else bool((out[:, 0, 0].cpu() == torch.arange(7.0)).all())
+        q.put((rank, ok1, ok2, ok3))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs 2 GPUs (RCCL over xGMI)")
+def test_two_rank_collectives_rccl():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[1] and r[2] and r[3] for r in res), res

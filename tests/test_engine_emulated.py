@@ -84,3 +84,14 @@ def test_pipeline_host_logic_matches_reference_video(emu, case):
     vid = pipe(i["ref_image"], list(i["poses"]), i["ref_pose"], i["W"], i["H"], i["L"], i["steps"], i["cfg"],
                latents=i["latents"], **i["kw"]).videos
     assert psnr(vid, gold[case + "/video_f16"].float()) >= 40.0
+    if case == "long_L4":
+        # display bytes made on the device == what save_videos_grid computes from the fp32 video on the host
+        # (src/utils/util.py:97-98: (x * 255).numpy().astype(np.uint8)); numpy output type as in the reference
+        u8 = pipe(i["ref_image"], list(i["poses"]), i["ref_pose"], i["W"], i["H"], i["L"], i["steps"], i["cfg"],
+                  latents=i["latents"], output_type="uint8", **i["kw"]).videos
+        want = (vid[0].permute(1, 2, 3, 0) * 255).numpy().astype("uint8")       # (L, H, W, 3)
+        assert u8.dtype == torch.uint8 and tuple(u8.shape) == (i["L"], i["H"], i["W"], 3)
+        assert (u8.numpy() == want).all()
+        arr = pipe(i["ref_image"], list(i["poses"]), i["ref_pose"], i["W"], i["H"], i["L"], i["steps"], i["cfg"],
+                   latents=i["latents"], output_type="numpy", return_dict=False, **i["kw"])
+        assert type(arr).__name__ == "ndarray" and (arr == vid.numpy()).all()

@@ -4,8 +4,10 @@ the north star's criterion: PSNR >= 40 dB on the decoded frames for identical we
 (reference loop: src/pipelines/pipeline_pose2vid_long.py:458-559).
 
   C1 in full          256x256, L=4, 10 DDIM steps, CFG 3.5                       (BASELINE configs[0])
-  windowed            256x256, L=24 -> two 16-frame windows, 2 steps              (the C4 mechanism at real width)
-  C2, reduced steps   512x512, L=16, 2 steps + ReferenceNet + 16 VAE frames      (BASELINE configs[1]; `slow`)
+  windowed            192x192, L=24 -> two 16-frame windows, 2 steps              (the C4 mechanism at real width)
+  C2, reduced steps   512x512, L=16, 1 step + ReferenceNet + VAE                  (BASELINE configs[1]; `slow`: the CPU
+                      oracle needs ~2.5 min per UNet3D call on the 32-frame CFG batch at this size, so the oracle decodes
+                      2 of the 16 frames; round 2's first GPU run did 2 steps x 16 frames: 46.4 dB, oracle 425 s)
   graph reuse         clip A, a different clip B (other image / poses / latents / resolution), clip A again through the
                       SAME pipeline object with the captured hipGraph active: every clip matches the oracle and A is
                       bit-identical before and after B (in-place bank / attn2 refresh, runner cache)
@@ -50,7 +52,8 @@ def _run(pipe, c, steps, cfg=3.5, **kw):
                 latents=c["latents"], **kw).videos
 
 
-def _oracle(pipe, sds, small, c, steps, cfg=3.5, **kw):
+def _oracle(pipe, sds, small, c, steps, cfg=3.5, decode_frames=None, **kw):
+    """decode_frames: the oracle decodes only these frame indices (its VAE costs 2.5 TFLOP per 512x512 frame)"""
     from aniportrait_amd import configs as C
     from oracle import ref_torch as O
     n = oracle_threads()
@@ -58,7 +61,9 @@ def _oracle(pipe, sds, small, c, steps, cfg=3.5, **kw):
     cfgs = {"unet": C.unet3d_kwargs(small), "vae": C.SD_VAE_SMALL if small else C.SD_VAE_FT_MSE}
     t0 = time.time()
     ref = O.pose2vid(sds, cfgs, clip, c["ref_image"], list(c["poses"]), c["ref_pose"], c["W"], c["H"], c["L"], steps, cfg,
-                     c["latents"], long=True, **kw)
+                     c["latents"], long=True, return_latents=decode_frames is not None, **kw)
+    if decode_frames is not None:
+        ref = O.decode_latents(sds["vae"], cfgs["vae"], ref[:, :, list(decode_frames)])
     return ref, time.time() - t0, n
 
 
@@ -87,26 +92,28 @@ def test_c1_in_full_and_graph_reuse_at_real_width(real_pipe):
 def test_windowed_long_clip_at_real_width(real_pipe):
     """two overlapping 16-frame context windows per step (the C4 mechanism) at real width"""
     pipe, sds = real_pipe
-    c = _clip(256, 256, 24, 1)
+    c = _clip(192, 192, 24, 1)
     vid = _run(pipe, c, 2)
     ref, secs, n = _oracle(pipe, sds, False, c, 2)
     p = psnr(vid, ref)
-    print(f"windowed 256x256 L=24 (2 windows) 2 steps: PSNR = {p:.2f} dB (oracle {secs:.0f} s on {n} threads)")
+    print(f"windowed 192x192 L=24 (2 windows) 2 steps: PSNR = {p:.2f} dB (oracle {secs:.0f} s on {n} threads)")
     assert p >= PSNR_BAR
 
 
 @pytest.mark.slow
 @torch.no_grad()
 def test_c2_reduced_steps_at_real_width(real_pipe):
-    """BASELINE configs[1] geometry (512x512, L=16, CFG 3.5) at 2 DDIM steps: ReferenceNet + 2 UNet3D calls on the
-    32-frame CFG batch + 16 VAE frames, everything at the sizes the bench runs"""
+    """BASELINE configs[1] geometry (512x512, L=16, CFG 3.5) at 1 DDIM step: VAE encode + ReferenceNet + PoseGuider on 16
+    frames + one UNet3D call on the 32-frame CFG batch (64x64 latents: T = 4096 tokens, head dims 40 / 80 / 160, reference
+    attention over 8192 keys) + VAE decode, everything at the sizes the bench runs; frames 0 and 9 against the oracle"""
     pipe, sds = real_pipe
     c = _clip(512, 512, 16, 2)
-    vid = _run(pipe, c, 2)
-    ref, secs, n = _oracle(pipe, sds, False, c, 2)
-    p = psnr(vid, ref)
-    print(f"C2 512x512 L=16 2 steps: PSNR = {p:.2f} dB (oracle {secs:.0f} s on {n} threads)")
-    assert p >= PSNR_BAR
+    vid = _run(pipe, c, 1)
+    frames = (0, 9)
+    ref, secs, n = _oracle(pipe, sds, False, c, 1, decode_frames=frames)
+    p = psnr(vid[:, :, list(frames)], ref)
+    print(f"C2 512x512 L=16 1 step, frames {frames}: PSNR = {p:.2f} dB (oracle {secs:.0f} s on {n} threads)")
+    assert vid.shape == (1, 3, 16, 512, 512) and p >= PSNR_BAR
 
 
 @torch.no_grad()
@@ -128,6 +135,14 @@ def test_two_different_clips_through_one_graph_small_width():
     # no-CFG clip in between (batch 1: other attn2 / bank buffers), then A again
     _run(pipe, a, 2, cfg=1.0)
     assert torch.equal(_run(pipe, a, 3), outs[0])
+    # output options: display bytes made on the device, and the frames draining asynchronously through pinned memory
+    u8 = pipe(a["ref_image"], list(a["poses"]), a["ref_pose"], a["W"], a["H"], a["L"], 3, 3.5, latents=a["latents"],
+              output_type="uint8").videos
+    assert (u8.numpy() == (outs[0][0].permute(1, 2, 3, 0) * 255).numpy().astype("uint8")).all()
+    pend = [pipe(c_["ref_image"], list(c_["poses"]), c_["ref_pose"], c_["W"], c_["H"], c_["L"], 3, 3.5,
+                 latents=c_["latents"], async_output=True).videos for c_ in (a, b, a)]   # three clips in flight
+    assert torch.equal(pend[0].result(), outs[0]) and torch.equal(pend[1].result(), outs[1])
+    assert torch.equal(pend[2].result(), outs[0])
     # the runner cache is bounded
     pipe.max_cached_graphs = 1
     _run(pipe, c, 2)

@@ -398,6 +398,20 @@ def test_window_accumulate_and_ddim():
     close(lat16, ref, "cfg+ddim step fp16 copy")
 
 
+def test_f16_to_u8_display_bytes():
+    """decoded frame -> display bytes == the reference's host arithmetic: fp16 (x / 2 + 0.5).clamp(0, 1) (its fp16 run,
+    pipeline_pose2vid_long.py:123), then fp32 (x * 255).astype(uint8) (src/utils/util.py:97-98)"""
+    ops = _ops()
+    x = (rnd(3, 16, 24, 3, seed=5) * 1.5).to(DEV)           # values beyond [-1, 1]: both clamps are exercised
+    got = ops.f16_to_u8(x, 0.5, 0.5).cpu()
+    ref16 = (x.cpu().float() * 0.5 + 0.5).clamp(0, 1).half()
+    want = (ref16.float() * 255).numpy().astype("uint8")
+    assert got.dtype == torch.uint8 and (got.numpy() == want).all()
+    odd = rnd(1003, seed=6).to(DEV)                          # tail path (n % 8 != 0)
+    assert (ops.f16_to_u8(odd, 0.5, 0.5).cpu().numpy() ==
+            ((odd.cpu().float() * 0.5 + 0.5).clamp(0, 1).half().float() * 255).numpy().astype("uint8")).all()
+
+
 def test_window_accumulate_wrapped_dilated_window():
     """a dilated window that wraps onto a frame twice (L=20, 16 frames, stride 2 -> 0,2,..,18,0,2,..,10): the
     reference's `noise_pred[:, :, c] = noise_pred[:, :, c] + pred` keeps the LAST occurrence and counts the frame once
