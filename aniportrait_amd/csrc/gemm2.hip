@@ -91,10 +91,18 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
   }
   const int bm = swz / nbn, bn = swz % nbn, m0 = bm * BM2, n0 = bn * BN;
 
-  // experiment (ANIP_GEMM2_DBG >> 8 = k): the blocks of every second dispatch round sleep k x 8128 cycles before they
-  // start, which puts the two blocks resident on a CU out of phase (one in its main loop while the other stores)
-  if ((dbg >> 8) != 0 && ((blockIdx.x >> 8) & 1))
-    for (int i = 0; i < (dbg >> 8); ++i) __builtin_amdgcn_s_sleep(127);
+  // experiment (ANIP_GEMM2_DBG bits 8-15 = k, bits 16-17 = who): a subset of the blocks sleeps k x 8128 cycles before
+  // it starts, to put blocks out of phase (some in their load-heavy main loop while others store).  who = 0: the second
+  // dispatch round (the co-resident partner on a CU), 1: odd XCDs (block id parity), 2: odd compute units (HW_ID.CU_ID)
+  if (((dbg >> 8) & 0xFF) != 0) {
+    const int who = (dbg >> 16) & 3;
+    bool late;
+    if (who == 0) late = (blockIdx.x >> 8) & 1;
+    else if (who == 1) late = blockIdx.x & 1;
+    else late = __builtin_amdgcn_s_getreg((4) | (8 << 6) | (3 << 11)) & 1;
+    if (late)
+      for (int i = 0; i < ((dbg >> 8) & 0xFF); ++i) __builtin_amdgcn_s_sleep(127);
+  }
 
   const f16* Ap = (const f16*)p.A;
   const f16* Wp = (const f16*)p.W;

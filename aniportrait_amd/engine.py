@@ -217,6 +217,32 @@ class RefState:
         self.pool = {}
 
 
+def project_reference_bank(net, p, ref):
+    """K_ref = to_k(bank), V_ref^T = to_v(bank)^T of one hooked block (transformer-block path p), written IN PLACE into
+    the block's per-shape buffers (src/models/mutual_self_attention.py:147-165 does this projection for every frame of
+    every step; the bank is constant over a clip)."""
+    C = ref.bank.shape[-1]
+    bank2 = ref.bank.reshape(-1, C)
+    if bank2.dtype != F16 or bank2.device != net.device:
+        bank2 = bank2.to(net.device, F16)
+    kbuf, vbuf = ref.buffers(bank2.shape[0], C, net.device)
+    ref.kref = ops.gemm(bank2, net.lin(p + ".attn1.to_k.weight"), out=kbuf)
+    ref.vtref = ops.gemm(bank2, net.lin(p + ".attn1.to_v.weight"), trans_out=True, out=vbuf)
+    ref.stale = False
+
+
+def prepare_reference(net, cfg, refs, ehs, attn2_cache):
+    """Everything of a denoising forward that depends on the CLIP token and the reference banks only — the bank
+    projections of the 16 hooked blocks and the collapsed attn2 vectors — refreshed in place, once per clip.  After it,
+    a captured hipGraph of the forward (which reads those buffers) is valid for every DDIM step of the clip, the first
+    one included."""
+    for p in attention_paths(cfg):
+        ref = refs.get(p)
+        if ref is not None and ref.mode == "read" and ref.bank is not None and (ref.kref is None or ref.stale):
+            project_reference_bank(net, p + ".transformer_blocks.0", ref)
+    attn2_cache.get(net, cfg, ehs, refresh=True)
+
+
 def transformer_block(net, p, h, Nf, T, heads, attn2_vec, rows_per_sample, ref=None, ref_index=None, stop_after_bank=False):
     """(Temporal)BasicTransformerBlock under ReferenceAttentionControl
     (src/models/attention.py:383-445, src/models/mutual_self_attention.py:93-265).  h (Nf*T, C)."""
@@ -233,13 +259,7 @@ def transformer_block(net, p, h, Nf, T, heads, attn2_vec, rows_per_sample, ref=N
     kw = {}
     if mode == "read" and ref.bank is not None:
         if ref.kref is None or ref.stale:
-            bank2 = ref.bank.reshape(-1, C)
-            if bank2.dtype != F16 or bank2.device != net.device:
-                bank2 = bank2.to(net.device, F16)
-            kbuf, vbuf = ref.buffers(bank2.shape[0], C, net.device)
-            ref.kref = ops.gemm(bank2, net.lin(p + ".attn1.to_k.weight"), out=kbuf)
-            ref.vtref = ops.gemm(bank2, net.lin(p + ".attn1.to_v.weight"), trans_out=True, out=vbuf)
-            ref.stale = False
+            project_reference_bank(net, p, ref)
         assert ref.bank.shape[1] == T, "reference bank token count differs from the denoising latents"
         kw = dict(kref=ref.kref, ldkr=C, vtref=ref.vtref, ldvtr=ref.vtref.shape[1], ref_index=ref_index[0],
                   n_ref_frames=ref_index[1])

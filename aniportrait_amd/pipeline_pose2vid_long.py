@@ -65,9 +65,9 @@ class _DenoiseRunner:
     """Static-buffer front of `UNet3DConditionModel.forward_nhwc` for one window shape (CFG batch S, f frames,
     latent h x w), kept on the pipeline across clips.  All per-call inputs live in persistent device buffers
     (x, timestep sinusoid, CLIP token, the 5 pose feature maps); the reference-bank projections and the
-    collapsed-attn2 vectors are refreshed IN PLACE by the eager forward of every clip's first DDIM step
-    (engine.transformer_block / engine.Attn2Cache).  That makes the forward — about 640 kernel launches —
-    a hipGraph captured once and replayed for every later (step, window, clip)."""
+    collapsed-attn2 vectors are refreshed IN PLACE once per clip (`set_clip` -> engine.prepare_reference: 32 small
+    GEMMs + 32 tiny matrix-vector products).  That makes the forward — about 640 kernel launches — a hipGraph
+    captured once and replayed for every (step, window, clip), each clip's first step included."""
 
     def __init__(self, unet, S, f, x, ehs, pose):
         dev = x.device
@@ -85,7 +85,9 @@ class _DenoiseRunner:
                 (pose is None or all(a.shape == b.shape for a, b in zip(self.pose, pose))))
 
     def set_clip(self, ehs):
+        """new clip: CLIP token into the static buffer, reference-bank projections / attn2 vectors refreshed in place"""
         self.ehs.copy_(ehs)
+        self.unet.prepare_reference(self.ehs)
 
     def set_pose(self, pose):
         if pose is not None:
@@ -97,12 +99,11 @@ class _DenoiseRunner:
             self.x[s_ * self.f:(s_ + 1) * self.f].copy_(x)
 
     def eager(self, x, temb):
-        """the clip's first forward: re-projects the reference banks and recomputes the collapsed-attn2 vectors from
-        this runner's CLIP token, both in place (buffers owned per shape by the UNet, never re-allocated)"""
+        """un-captured forward (profilers / ANIP_NO_GRAPH): same static buffers, same in-place reference state"""
         self._fill_x(x)
         self.temb.copy_(temb)
         return self.unet.forward_nhwc(self.x, self.S, self.f, None, self.ehs, self.pose, temb_in=self.temb,
-                                      attn2_refresh=True)
+                                      attn2_refresh=False)
 
     def replay(self, x, temb):
         self._fill_x(x)
@@ -453,9 +454,9 @@ class Pose2VideoPipeline(_Base):
         # per-step window sums: acc (S, L, HWC) and counter (L,) are views of one flat buffer (one in-place all-reduce)
         sums_flat, acc, counter = D.window_sum_buffers(S, L, HWC, device)
         single = len(windows) == 1 and windows[0] == list(range(L))
-        # Denoising UNet forwards run through a persistent _DenoiseRunner (static input buffers).  Step 0 is eager
-        # (it re-projects the reference banks / attn2 vectors in place); later steps replay the runner's hipGraph,
-        # captured once per window shape and reused across clips.
+        # Denoising UNet forwards run through a persistent _DenoiseRunner (static input buffers): `set_clip` refreshes the
+        # reference-bank projections / attn2 vectors in place, then every step replays the runner's hipGraph, captured
+        # once per window shape and reused across clips.
         ucfg = self.denoising_unet.config
         temb_table = torch.stack([engine.timestep_sinusoid(t, S, ucfg["block_out_channels"][0], "cpu",
                                                            ucfg.get("flip_sin_to_cos", True), ucfg.get("freq_shift", 0))
@@ -493,9 +494,9 @@ class Pose2VideoPipeline(_Base):
                     r = runner_for(k)
                     if not single:
                         r.set_pose(pose_features(k))
-                    pred = r.replay(x, temb_table[i]) if (use_graph and i >= 1) else r.eager(x, temb_table[i])
+                    pred = r.replay(x, temb_table[i]) if use_graph else r.eager(x, temb_table[i])
                     if i <= 1:
-                        tm.mark(f"unet_step{i}" + ("(eager)" if not (use_graph and i >= 1) else "(graph)"))
+                        tm.mark(f"unet_step{i}" + ("(graph)" if use_graph else "(eager)"))
                     ops.window_accumulate(pred, acc, counter, acc_idx[k], S, len(c), L, HWC)
                 if ws > 1:
                     # also for a single window: the ranks that own no window hold zeros (acc / counter = 0 / 0

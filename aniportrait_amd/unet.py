@@ -118,6 +118,11 @@ class _UNetBase(HipModel):
             if v is not None:
                 raise NotImplementedError(f"{type(self).__name__}.forward: `{k}` is not part of the pose2vid hot path")
 
+    def prepare_reference(self, encoder_hidden_states):
+        """refresh (in place) the reference-bank projections and collapsed-attn2 vectors for a new clip — see
+        engine.prepare_reference; later `forward_nhwc(..., attn2_refresh=False)` calls / graph replays reuse them"""
+        engine.prepare_reference(self.packed(), self.config, self._engine_refs(), encoder_hidden_states, self._attn2_cache)
+
     def forward_nhwc(self, x, b, f, timestep, encoder_hidden_states, pose_nhwc=None, final=True,
                      stop_after_last_bank=False, temb_in=None, attn2_refresh=True):
         """channels-last entry used by the pipeline: x (b*f, h, w, C) fp16 on the GPU.  temb_in: device fp32
