@@ -340,13 +340,12 @@ __global__ __launch_bounds__(NT, (D > 96 ? 1 : 2)) void ref_attn_kernel(const Re
   }
 }
 
-// query groups per wave: 2 where the head dim leaves the registers for it (d <= 64) and the frame has enough query
-// blocks to fill the chip either way; ANIP_ATTN_QH=1|2 overrides (kernel experiments)
+// query groups per wave: 1; ANIP_ATTN_QH=2 selects the two-group variant (d <= 40) for kernel experiments
 template <int D>
 int launch_ref_attn(const RefAttnArgs& a, int Nf, hipStream_t stream) {
   static const int force_qh = getenv("ANIP_ATTN_QH") ? atoi(getenv("ANIP_ATTN_QH")) : 0;
-  constexpr bool CAN2 = D <= 64;
-  const bool two = CAN2 && (force_qh ? force_qh == 2 : (a.T >= 1024));
+  constexpr bool CAN2 = D <= 40;
+  const bool two = CAN2 && force_qh == 2;   // measured on MI355X (d = 40, T = 4096): no faster than one group per wave at twice the occupancy
   dim3 grid((unsigned)((a.T + (two ? 255 : 127)) / (two ? 256 : 128)), (unsigned)a.heads, (unsigned)Nf);
   AnipProfScope prof_(ANIP_K_REF_ATTN, (void*)stream);
   const bool fits32 = (int64_t)KV * a.ldk < (1ll << 31) && (int64_t)KV * a.ldkr < (1ll << 31) &&

@@ -8,6 +8,11 @@
 // clip), so the engine only uses it with ANIP_FUSED_FFN=1.  Known weakness: every 64-deep K-tile iteration drains the
 // DMA queue (vmcnt(0) + barrier) with only 16 MFMAs per wave to cover it.
 //
+// Round 2: enabled by default (engine._FUSED_FFN) — with every DDIM step inside the captured graph it is 1-4 % faster end
+// to end than the two-GEMM path.  A variant with a continuous 3-stage W1 ring under counted vmcnt and the W2 chunk
+// loaded straight into registers (no per-K-tile drain) was built and measured: 516 us vs 440 us for this kernel
+// (profiles/r02: exp_ffn) — the G phase is not latency-bound, so the variant was dropped.
+//
 // Why: at C = 320 (the 64x64 level) the two GEMMs cost 332 + 194 us per layer and are bound by memory traffic, not by
 // the matrix pipe: the GEGLU output H (M x 4C fp16 = 335 MB) is written to HBM and read back, and the second GEMM
 // streams it as its A operand.  Here H never leaves the CU.

@@ -2,6 +2,8 @@
 // LayerNorm (+ fused temporal positional encoding), fp32 row softmax.
 // Channels-last fp16 activations, fp32 statistics, 16-B vector loads/stores, deterministic
 // two-level reductions (no atomics).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -149,6 +151,91 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const f16* __restrict__ x1
 }
 
 // ---------------------------------------------------------------------------------------------
+// GroupNorm in ONE launch: one block per (image n, group g) walks the group's slab — HW rows of cpg = C/G channels —
+// twice: sum / sum of squares, then normalise (+SiLU) and store.  The second walk hits L2 (a slab is 5 .. 160 KB), so
+// HBM sees the tensor once in and once out, and the separate statistics pass with its (image, chunk, group) workspace
+// and second launch disappears.  V = halfs per vector (2, 4 or 8: what cpg and the group's byte offset allow).
+// Block -> (n, g): the four groups 4x .. 4x+3 of an image run on XCD x (block id % 8), so the 64 / 128-B lines that
+// adjacent groups share are fetched into one L2, not eight.
+// ---------------------------------------------------------------------------------------------
+template <int V>
+__global__ __launch_bounds__(NT) void gn_slab_kernel(const f16* __restrict__ x1, int C1, const f16* __restrict__ x2, int C2,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    f16* __restrict__ y, int64_t HW, int G, float eps, int silu) {
+  typedef unsigned int uvec __attribute__((ext_vector_type(V / 2)));
+  union VH { uvec u; f16 e[V]; };
+  __shared__ float red[2][NT / 64];
+  __shared__ float sc[256], sh[256];     // cpg <= 256
+  const int tid = threadIdx.x;
+  const int C = C1 + C2, cpg = C / G, vpr = cpg / V;
+  int g, n;
+  if ((G & 31) == 0) {                   // XCD-aware: block b -> xcd = b % 8 owns groups (G/8) * xcd .. of every image
+    const int b = blockIdx.x, xcd = b & 7, k = b >> 3, gpx = G >> 3;
+    g = xcd * gpx + (k % gpx);
+    n = k / gpx;
+  } else {
+    g = blockIdx.x % G;
+    n = blockIdx.x / G;
+  }
+  const int c0 = g * cpg;
+  const int64_t nvec = HW * vpr;
+  const f16* b1 = x1 + (int64_t)n * HW * C1;
+  const f16* b2 = x2 ? x2 + (int64_t)n * HW * C2 : nullptr;
+  float s = 0.f, q = 0.f;
+  for (int64_t v = tid; v < nvec; v += NT) {
+    const int64_t row = v / vpr;
+    const int c = c0 + (int)(v - row * vpr) * V;
+    const f16* src = c < C1 ? b1 + row * C1 + c : b2 + row * C2 + (c - C1);
+    VH t;
+    t.u = *(const uvec*)src;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const float f = (float)t.e[e];
+      s += f;
+      q += f * f;
+    }
+  }
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if ((tid & 63) == 0) {
+    red[0][tid >> 6] = s;
+    red[1][tid >> 6] = q;
+  }
+  __syncthreads();
+  float S = 0.f, Q = 0.f;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) {
+    S += red[0][w];
+    Q += red[1][w];
+  }
+  const float cnt = (float)((double)HW * cpg);
+  const float mean = S / cnt;
+  const float rstd = rsqrtf(fmaxf(Q / cnt - mean * mean, 0.f) + eps);
+  for (int c = tid; c < cpg; c += NT) {
+    const float a = rstd * gamma[c0 + c];
+    sc[c] = a;
+    sh[c] = beta[c0 + c] - mean * a;
+  }
+  __syncthreads();
+  f16* yb = y + (int64_t)n * HW * C;
+  for (int64_t v = tid; v < nvec; v += NT) {
+    const int64_t row = v / vpr;
+    const int cl = (int)(v - row * vpr) * V;
+    const int c = c0 + cl;
+    const f16* src = c < C1 ? b1 + row * C1 + c : b2 + row * C2 + (c - C1);
+    VH t, o;
+    t.u = *(const uvec*)src;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      float f = (float)t.e[e] * sc[cl + e] + sh[cl + e];
+      if (silu) f = silu_f(f);
+      o.e[e] = (f16)f;
+    }
+    *(uvec*)(yb + row * C + c) = o.u;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // LayerNorm: G lanes (power of two) cooperate on one row, 64/G rows per wave, so that every lane is
 // busy for any channel count: lane l of a group owns the 16-B chunks l, l+G, l+2G, ... (NCH of them,
 // kept in registers between the mean pass and the variance pass).  C % 8 == 0, C <= 2560.
@@ -292,6 +379,31 @@ extern "C" int anip_groupnorm(const void* x1, int C1, const void* x2, int C2, co
   ANIP_REQUIRE((C1 & 7) == 0 && (C2 & 7) == 0 && C % G == 0, "anip_groupnorm: C1=%d C2=%d must be multiples of 8, C %% G == 0", C1, C2);
   ANIP_REQUIRE((C2 == 0) == (x2 == nullptr), "anip_groupnorm: x2/C2 mismatch");
   ANIP_REQUIRE(C <= 8192, "anip_groupnorm: C=%d too large", C);
+  // single-launch form for the 8x8 / 16x16 levels (measured on MI355X, 32 frames, stats + apply vs one slab kernel:
+  // 16x16 C1280 27.8 -> 18.7 us, C2560 46.7 -> 31.5, 8x8 C1280 19.3 -> 14.6, C2560 29.9 -> 15.6; from 32x32 up the
+  // slab's narrow row segments (cpg * 2 = 20 .. 120 B) lose to the two coalesced passes: 64x64 C320 57 -> 147 us).
+  // ANIP_GN_SLAB_HW overrides the row limit (0 disables).
+  {
+    static const int slab_hw = getenv("ANIP_GN_SLAB_HW") ? atoi(getenv("ANIP_GN_SLAB_HW")) : 256;
+    const int cpg = C / G;
+    if (slab_hw > 0 && HW <= slab_hw && cpg <= 256 && (cpg & 1) == 0 && (int64_t)N * G >= 256) {
+      const int V = ((cpg & 7) == 0) ? 8 : ((cpg & 3) == 0) ? 4 : 2;
+      AnipProfScope prof_(ANIP_K_GN_APPLY, (void*)stream);
+      const dim3 grid((unsigned)(N * G));
+      hipStream_t st = (hipStream_t)stream;
+      if (V == 8)
+        hipLaunchKernelGGL(gn_slab_kernel<8>, grid, dim3(NT), 0, st, (const f16*)x1, C1, (const f16*)x2, C2, gamma, beta,
+                           (f16*)y, HW, G, eps, silu);
+      else if (V == 4)
+        hipLaunchKernelGGL(gn_slab_kernel<4>, grid, dim3(NT), 0, st, (const f16*)x1, C1, (const f16*)x2, C2, gamma, beta,
+                           (f16*)y, HW, G, eps, silu);
+      else
+        hipLaunchKernelGGL(gn_slab_kernel<2>, grid, dim3(NT), 0, st, (const f16*)x1, C1, (const f16*)x2, C2, gamma, beta,
+                           (f16*)y, HW, G, eps, silu);
+      ANIP_LAUNCH_CHECK("anip_groupnorm(slab)");
+      return 0;
+    }
+  }
   int nchunks;
   int64_t ppc;
   gn_chunks(N, HW, &nchunks, &ppc);

@@ -90,6 +90,14 @@ class PackedNet:
             self.t[k] = ops.pack_conv_direct(self._raw(name).to(self.device, F16))
         return self.t[k]
 
+    def scalar(self, name):
+        """a one-element parameter as a Python float, read back once (a device-to-host copy per call would synchronise
+        every forward and is not allowed while a stream is capturing)"""
+        k = ("scalar", name)
+        if k not in self.t:
+            self.t[k] = float(self._raw(name).float().reshape(-1)[0])
+        return self.t[k]
+
     def scaled_f32(self, name, scale):
         k = ("sf32", name, float(scale))
         if k not in self.t:
@@ -172,10 +180,11 @@ def resnet(net, p, x, skip, temb_rb, rows_per_group, eps, groups=32):
                        residual=sc)
 
 
-# single-kernel feed-forward at C = 320 (csrc/ffn.hip): bit-identical to the two-GEMM path and 435 vs 644 us in
-# isolation, but the one end-to-end run that fit in round 1's GPU budget was slower with it (1.70 vs 1.62 s per clip),
-# so it stays opt-in (ANIP_FUSED_FFN=1) until that is understood
-_FUSED_FFN = os.environ.get("ANIP_FUSED_FFN", "0") == "1"
+# single-kernel feed-forward at C = 320 (csrc/ffn.hip): FF1 + GEGLU + FF2 + residual without the M x 4C intermediate
+# leaving the CU (335 MB written and read back per 64x64 layer otherwise); bit-identical to the two-GEMM path and, since
+# round 2 (every step inside the captured graph), 1-4 % faster end to end (10.39 / 10.41 vs 9.99 / 10.31 frames/s in two
+# paired runs).  ANIP_FUSED_FFN=0 selects the two-GEMM path.
+_FUSED_FFN = os.environ.get("ANIP_FUSED_FFN", "1") == "1"
 
 
 def feed_forward(net, p, n_in, residual):
@@ -592,7 +601,7 @@ def pose_guider_forward(net, stacks, x, training, use_ca):
 
     x = stack("conv_layers", x)
     N, H, W, C = x.shape
-    scale = float(net.sd["scale"].detach().float().reshape(-1)[0])
+    scale = net.scalar("scale")
     # final_proj(x) * scale  ==  scale * (x W^T) + scale * b   (pose_guider.py:129-131)
     x = ops.gemm(x.reshape(N * H * W, C), net.lin("final_proj.weight"), net.scaled_f32("final_proj.bias", scale),
                  alpha=scale).reshape(N, H, W, -1)

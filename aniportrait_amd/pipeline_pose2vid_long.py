@@ -109,6 +109,11 @@ class _DenoiseRunner:
         self._fill_x(x)
         self.temb.copy_(temb)
         if self.graph is None:
+            # one un-captured forward first: it fills every lazy cache of the path (packed weights, reference-index
+            # tensors, LDS-size attributes of the kernels) — host-to-device copies and allocations that are not allowed
+            # while the stream is capturing
+            self.unet.forward_nhwc(self.x, self.S, self.f, None, self.ehs, self.pose, temb_in=self.temb,
+                                   attn2_refresh=False)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self.pred = self.unet.forward_nhwc(self.x, self.S, self.f, None, self.ehs, self.pose,
@@ -116,6 +121,38 @@ class _DenoiseRunner:
             self.graph = g
         self.graph.replay()
         return self.pred
+
+
+class _GraphedFn:
+    """`fn(*static_inputs) -> list of tensors` behind static buffers: one un-captured call first (it fills the lazy
+    caches of the path: packed weights, kernel attributes — host work that is illegal while a stream captures), then a
+    hipGraph captured once and replayed for every later call with same-shaped inputs.  The once-per-clip networks
+    (ReferenceNet: ~350 launches for 1.6 TFLOP; PoseGuider) are launch-bound when issued eagerly.  The outputs are the
+    graph's own buffers: valid until the next call."""
+
+    def __init__(self, fn, inputs):
+        self.fn = fn
+        self.static = [torch.empty_like(t) for t in inputs]
+        self.graph = None
+        self.out = None
+
+    def matches(self, inputs):
+        return len(inputs) == len(self.static) and all(a.shape == b.shape and a.dtype == b.dtype and a.device == b.device
+                                                       for a, b in zip(self.static, inputs))
+
+    def __call__(self, inputs, use_graph=True):
+        for dst, src in zip(self.static, inputs):
+            dst.copy_(src)
+        if not use_graph:
+            return self.fn(*self.static)
+        if self.graph is None:
+            self.fn(*self.static)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.out = self.fn(*self.static)
+            self.graph = g
+        self.graph.replay()
+        return self.out
 
 
 class PendingVideo:
@@ -341,9 +378,50 @@ class Pose2VideoPipeline(_Base):
         return self.__dict__["_runners"]
 
     def drop_cached_graphs(self):
-        """release every captured denoising graph and its static buffers"""
+        """release every captured graph (denoising step, ReferenceNet, PoseGuider) and its static buffers"""
         self.__dict__["_runners"] = OrderedDict()
         self.__dict__.pop("_runner_tag", None)
+        self.__dict__["_aux_graphs"] = {}
+
+    def _aux_graph(self, kind, module, key, make):
+        """{(kind, key): _GraphedFn} for the once-per-clip networks; an entry dies with the module's packed weights
+        (their addresses are baked into the graph) and the per-kind population is bounded like the step graphs"""
+        cache = self.__dict__.setdefault("_aux_graphs", {})
+        tag = (id(module), id(module.packed()))
+        live = {k: v for k, v in cache.items() if k[0] != kind or v[0] == tag}
+        mine = [k for k in live if k[0] == kind]
+        if (kind, key) not in live:
+            while len(mine) >= max(1, int(self.max_cached_graphs)):
+                live.pop(mine.pop(0))
+            live[(kind, key)] = (tag, make())
+        self.__dict__["_aux_graphs"] = live
+        return live[(kind, key)][1]
+
+    def _reference_banks(self, ref_lat, S, ehs, use_graph):
+        """ReferenceNet pass at t = 0 in write mode (pipeline_pose2vid_long.py:474-485): fills `module.bank` of the 16
+        hooked blocks.  Only the banks matter, so the pass stops after the last bank write."""
+        unet = self.reference_unet
+        blocks = [rb for rb in unet._ref_blocks.values() if rb.state.mode == "write"]
+        x = ref_lat.repeat(S, 1, 1, 1).contiguous()
+        if not use_graph:
+            unet.forward_nhwc(x, S, 1, 0, ehs, None, final=False, stop_after_last_bank=True)
+            return
+        dev = x.device
+        temb0 = engine.timestep_sinusoid(0, S, unet.config["block_out_channels"][0], dev,
+                                         unet.config.get("flip_sin_to_cos", True), unet.config.get("freq_shift", 0))
+
+        def fn(xs, es):
+            for rb in blocks:
+                rb.node.bank = []
+            unet.forward_nhwc(xs, S, 1, None, es, None, final=False, stop_after_last_bank=True, temb_in=temb0)
+            banks = [rb.node.bank[-1] for rb in blocks]
+            for rb in blocks:
+                rb.node.bank = []
+            return banks
+
+        g = self._aux_graph("refnet", unet, (S, tuple(x.shape), str(dev), len(blocks)), lambda: _GraphedFn(fn, [x, ehs]))
+        for rb, bank in zip(blocks, g([x, ehs])):
+            rb.node.bank = [bank]
 
     @staticmethod
     def _require_gpu(device):
@@ -422,9 +500,11 @@ class Pose2VideoPipeline(_Base):
 
         # ReferenceNet: one pass at t = 0 (pipeline_pose2vid_long.py:474-485); only the banks matter, so
         # the pass stops after the last bank write.  With a dp_group, rank 0 computes and broadcasts.
+        # (ANIP_NO_GRAPH=1: eager launches, for profilers whose counter collection cannot follow graph replays)
+        use_graph = (bool(use_graph) and device.type == "cuda" and ops._WORK is None and
+                     not os.environ.get("ANIP_NO_GRAPH"))
         if rank == 0 or ws == 1:
-            self.reference_unet.forward_nhwc(ref_lat.repeat(S, 1, 1, 1).contiguous(), S, 1, 0, ehs, None,
-                                             final=False, stop_after_last_bank=True)
+            self._reference_banks(ref_lat, S, ehs, use_graph)
         if ws > 1:
             self._broadcast_banks(writer, S, h, w, dp_group, device)
         reader.update(writer)
@@ -446,9 +526,16 @@ class Pose2VideoPipeline(_Base):
                 c = windows[k]
                 # batch 1: the CFG duplication does not change train-mode BatchNorm statistics; ref_pose never
                 # reaches the arithmetic (pose_guider.py: cross_attention_dim=None => no attn2)
-                fea = pg.forward_nhwc(pose_nhwc if (pose_nhwc.shape[0] == L and c == list(range(L))) else
-                                      pose_nhwc[torch.tensor(c, dtype=torch.long, device=device)])
-                pose_cache[k] = [n.repeat(S, 1, 1, 1).contiguous() if S > 1 else n for n in fea]
+                frames = (pose_nhwc if (pose_nhwc.shape[0] == L and c == list(range(L))) else
+                          pose_nhwc[torch.tensor(c, dtype=torch.long, device=device)])
+                if use_graph:
+                    g = self._aux_graph("pose", pg, (tuple(frames.shape), str(device), bool(pg.training)),
+                                        lambda: _GraphedFn(lambda x: list(pg.forward_nhwc(x)), [frames]))
+                    fea = g([frames])
+                else:
+                    fea = pg.forward_nhwc(frames)
+                # the graph's outputs are overwritten by the next window's replay: keep copies
+                pose_cache[k] = [n.repeat(S, 1, 1, 1).contiguous() if S > 1 else n.clone() for n in fea]
             return pose_cache[k]
 
         # per-step window sums: acc (S, L, HWC) and counter (L,) are views of one flat buffer (one in-place all-reduce)
@@ -461,9 +548,6 @@ class Pose2VideoPipeline(_Base):
         temb_table = torch.stack([engine.timestep_sinusoid(t, S, ucfg["block_out_channels"][0], "cpu",
                                                            ucfg.get("flip_sin_to_cos", True), ucfg.get("freq_shift", 0))
                                   for t in timesteps]).to(device)
-        # (ANIP_NO_GRAPH=1: eager launches, for profilers whose counter collection cannot follow graph replays)
-        use_graph = (bool(use_graph) and device.type == "cuda" and ops._WORK is None and
-                     not os.environ.get("ANIP_NO_GRAPH"))
         runners = self._get_runners()
         clip_runners = {}
 

@@ -188,6 +188,11 @@ def test_conv_small(Cin, Cout, ks):
     (3, 50, 64, 0, True, 1e-5, 0.0), (2, 256, 320, 0, True, 1e-5, 0.0), (2, 64, 128, 64, True, 1e-5, 0.0),
     (2, 4, 1280, 1280, True, 1e-5, 0.0), (1, 4096, 128, 0, False, 1e-6, 3.0), (2, 100, 640, 320, False, 1e-6, 0.0),
     (1, 70000, 64, 0, True, 1e-6, 0.5),
+    # enough (image, group) slabs to take the single-launch kernel: every vector width (cpg % 8 / % 4 / % 2), a group
+    # straddling the two sources (cpg = 30), the UNet's own shapes at a reduced frame count
+    (8, 64, 1280, 0, True, 1e-5, 0.0), (8, 256, 640, 320, True, 1e-5, 0.5), (16, 1024, 320, 0, False, 1e-6, 3.0),
+    (8, 100, 1280, 1280, True, 1e-5, 0.0), (8, 4096, 320, 0, True, 1e-5, 1.0), (8, 256, 640, 0, False, 1e-6, 0.0),
+    (8, 1024, 1280, 640, True, 1e-5, 0.0),
 ])
 def test_groupnorm(N, HW, C1, C2, silu, eps, shift):
     ops = _ops()

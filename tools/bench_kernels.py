@@ -153,8 +153,14 @@ def main():
         bench_attn(NF, 64, 8, 160, "8^2 d160")
     if want("norm"):
         bench_gn(NF, 4096, 320, "64^2 C320")
+        bench_gn(NF, 4096, 640, "64^2 C640")
         bench_gn(NF, 4096, 960, "64^2 C960")
         bench_gn(NF, 1024, 640, "32^2 C640")
+        bench_gn(NF, 1024, 1920, "32^2 C1920")
+        bench_gn(NF, 256, 1280, "16^2 C1280")
+        bench_gn(NF, 256, 2560, "16^2 C2560")
+        bench_gn(NF, 64, 1280, "8^2 C1280")
+        bench_gn(NF, 64, 2560, "8^2 C2560")
         bench_gn(16, 262144, 128, "vae 512^2 C128")
         bench_ln(NF * 4096, 320, "64^2 C320")
         bench_ln(NF * 1024, 640, "32^2 C640")
