@@ -833,9 +833,11 @@ int anip_gemm2_try(const anip_gemm_params& p, hipStream_t stream) {
 
   // wide tiles (256 x 320 / 256 x 256, BK = 64): every K-tile inside one conv tap / one A source, N padded < 15 %,
   // and K long enough that the main loop (not the per-tile prologue / epilogue, where two resident blocks per CU
-  // overlap better) dominates — measured crossover between K = 640 and K = 1280
+  // overlap better) dominates — measured crossover between K = 320 and K = 640
   const bool k64 = p.conv ? (p.Cin % 64 == 0) : (p.A2 == nullptr || p.K1 % 64 == 0);
-  if (k64 && force != 1 && (p.K >= 1024 || force == 2)) {
+  // (round 2 microbench, 32 frames: K = 640 layers of the 32x32 level 10-12 % faster on the wide tiles — ff-in GEGLU
+  // 307 -> 272 us, temporal qkv 122 -> 107, out-proj 59.9 -> 54.0; K = 320 layers no better, some worse)
+  if (k64 && force != 1 && (p.K >= 640 || force == 2)) {
     const int64_t pad320 = (int64_t)((p.N + 319) / 320) * 320, pad256 = (int64_t)((p.N + 255) / 256) * 256;
     int wbn = 0;
     if (p.act == 1) wbn = (pad256 * 100 <= (int64_t)p.N * 115) ? 256 : 0;   // GEGLU pairs tiles: even count per wave
