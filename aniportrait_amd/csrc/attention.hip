@@ -91,12 +91,28 @@ __global__ __launch_bounds__(NT, (D > 96 ? 1 : 2)) void ref_attn_kernel(const Re
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int ql = lane & 31, hi = lane >> 5;
   const int T = a.T;
-  const int h = blockIdx.y, n = blockIdx.z;
+  // Block -> (query block, head, frame).  Workgroups are dealt round-robin to the 8 XCDs in launch order (x fastest),
+  // and every XCD has its own L2: with the natural order the query blocks of one (frame, head) — which all stream the
+  // same K / V^T — land on all 8 L2s and each fetches that K / V^T from the fabric (rocprofv3 FETCH_SIZE: 2.1 GB per
+  // launch at 64x64, d = 40, against 0.26 GB of operands).  When the (frame, head) count divides by 8, the launch order
+  // is re-read so that XCD x owns (frame, head) pairs x, x + 8, ... with all their query blocks.
+  int qb = blockIdx.x, h = blockIdx.y, n = blockIdx.z;
+  {
+    const int nqb = gridDim.x, nfh = gridDim.y * gridDim.z;
+    if ((nfh & 7) == 0) {
+      const int lin = blockIdx.x + nqb * (blockIdx.y + gridDim.y * blockIdx.z);
+      const int xcd = lin & 7, k = lin >> 3;
+      const int fh = (k / nqb) * 8 + xcd;
+      qb = k % nqb;
+      h = fh % gridDim.y;
+      n = fh / gridDim.y;
+    }
+  }
   int q[QH];
   bool qvalid[QH];
 #pragma unroll
   for (int g = 0; g < QH; ++g) {
-    q[g] = blockIdx.x * QPB + wave * (32 * QH) + g * 32 + ql;
+    q[g] = qb * QPB + wave * (32 * QH) + g * 32 + ql;
     qvalid[g] = q[g] < T;
   }
   const int ref = a.ref_index ? a.ref_index[n] : -1;
@@ -372,39 +388,69 @@ int launch_ref_attn(const RefAttnArgs& a, int Nf, hipStream_t stream) {
 // rows (LDS broadcast) and write neighbouring output segments — computes its 1 x F score row with v_dot2_f32_f16,
 // the softmax in registers and the d outputs 8 channels at a time (fp16 inputs, fp32 accumulation).
 // ---------------------------------------------------------------------------------------------------
+// (round 2) The kernel is VALU-bound (rocprofv3: SQ_ACTIVE_INST_VALU > 100 % of a SIMD's cycles over its waves, no
+// MFMA), and 4/5 of that was P V: one v_cvt + one v_fma per (key, channel).  V is therefore staged as KEY PAIRS —
+// (v[2j][c], v[2j+1][c]) packed in one dword, interleaved with v_perm while the two frames' 16-B chunks are on their
+// way to LDS — and the probabilities are packed to fp16 pairs once per query, so P V is one v_dot2_f32_f16 per
+// (key pair, channel) with fp32 accumulation: 4x fewer VALU instructions.  (The probabilities of the reference's fp16
+// SDPA are fp16 too.)
 template <int FMAX>
 __global__ __launch_bounds__(NT) void temporal_attn_kernel(const f16* __restrict__ qkv, f16* __restrict__ out, int B,
                                                           int F, int T, int heads, int d, float scale_log2e, int hpg,
                                                           int SL) {
   extern __shared__ __attribute__((aligned(16))) char dsm[];
+  constexpr int FP = FMAX / 2;              // key pairs
   const int tid = threadIdx.x;
   const int C = heads * d, CG = hpg * d, ngroups = heads / hpg;
   const int g = blockIdx.x % ngroups;
   const int64_t bt = blockIdx.x / ngroups;
   const int t = (int)(bt % T), b = (int)(bt / T);
-  f16* sq = (f16*)dsm;
-  f16* sk = sq + F * CG;
-  f16* sv = sk + F * CG;
-  const int cpr = CG >> 3;                 // 16-B chunks per (frame, q|k|v) segment
-  const int total = F * 3 * cpr;
-  // all of a thread's loads are issued before the first LDS store (8 per batch): one memory latency per batch,
-  // not one per 16 bytes
-  for (int base = 0; base < total; base += NT * 8) {
-    u32x4 v[8];
-    int dst[8];
+  const int F2 = (F + 1) >> 1;               // frame pairs staged
+  f16* sq = (f16*)dsm;                       // [2*F2][CG]
+  f16* sk = sq + 2 * F2 * CG;                // [2*F2][CG]
+  f16* sv = sk + 2 * F2 * CG;                // [F2][CG] key pairs: 2 halfs per channel
+  const int cpr = CG >> 3;                   // 16-B chunks per (frame, q|k|v) segment
+  const int total = F2 * 3 * cpr;            // items: (frame pair, segment, chunk)
+  for (int base = 0; base < total; base += NT * 4) {
+    u32x4 va[4], vb[4];
+    int fp_[4], seg_[4], off_[4];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < 4; ++u) {
       const int c = base + u * NT + tid;
       const bool ok = c < total;
       const int cc = ok ? c : 0;
-      const int f = cc / (3 * cpr), r = cc - f * (3 * cpr);
+      const int fp = cc / (3 * cpr), r = cc - fp * (3 * cpr);
       const int seg = r / cpr, off = r - seg * cpr;
-      dst[u] = ok ? (seg * F + f) * CG + off * 8 : -1;
-      v[u] = *(const u32x4*)(qkv + (((int64_t)b * F + f) * T + t) * (3 * (int64_t)C) + seg * C + g * CG + off * 8);
+      fp_[u] = ok ? fp : -1;
+      seg_[u] = seg;
+      off_[u] = off;
+      const int f0 = 2 * fp, f1 = min(2 * fp + 1, F - 1);   // odd F: the missing partner re-reads the last frame
+      va[u] = *(const u32x4*)(qkv + (((int64_t)b * F + f0) * T + t) * (3 * (int64_t)C) + seg * C + g * CG + off * 8);
+      vb[u] = *(const u32x4*)(qkv + (((int64_t)b * F + f1) * T + t) * (3 * (int64_t)C) + seg * C + g * CG + off * 8);
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (dst[u] >= 0) *(u32x4*)(sq + dst[u]) = v[u];
+    for (int u = 0; u < 4; ++u) {
+      if (fp_[u] < 0) continue;
+      if (seg_[u] < 2) {
+        f16* dst = (seg_[u] == 0 ? sq : sk) + (2 * fp_[u]) * CG + off_[u] * 8;
+        *(u32x4*)dst = va[u];
+        *(u32x4*)(dst + CG) = vb[u];
+      } else {
+        // (a0 a1 | a2 a3 | ..) x (b0 b1 | ..) -> (a0 b0 | a1 b1 | a2 b2 | ...): low / high halves of each dword pair
+        u32x4 lo, hi;
+        lo.x = __builtin_amdgcn_perm(vb[u].x, va[u].x, 0x05040100u);
+        lo.y = __builtin_amdgcn_perm(vb[u].x, va[u].x, 0x07060302u);
+        lo.z = __builtin_amdgcn_perm(vb[u].y, va[u].y, 0x05040100u);
+        lo.w = __builtin_amdgcn_perm(vb[u].y, va[u].y, 0x07060302u);
+        hi.x = __builtin_amdgcn_perm(vb[u].z, va[u].z, 0x05040100u);
+        hi.y = __builtin_amdgcn_perm(vb[u].z, va[u].z, 0x07060302u);
+        hi.z = __builtin_amdgcn_perm(vb[u].w, va[u].w, 0x05040100u);
+        hi.w = __builtin_amdgcn_perm(vb[u].w, va[u].w, 0x07060302u);
+        f16* dst = sv + ((int64_t)fp_[u] * CG + off_[u] * 8) * 2;
+        *(u32x4*)dst = lo;
+        *(u32x4*)(dst + 8) = hi;
+      }
+    }
   }
   __syncthreads();
   // thread = (item, d-slice): item = (query frame i, head h), h fastest; the head's d/8 chunks are split over SL
@@ -447,22 +493,30 @@ __global__ __launch_bounds__(NT) void temporal_attn_kernel(const f16* __restrict
   float sum = 0.f;
 #pragma unroll
   for (int j = 0; j < FMAX; ++j) {
-    s[j] = (j < F) ? __builtin_amdgcn_exp2f((s[j] - mx) * scale_log2e) : 0.f;
+    s[j] = (j < F) ? __builtin_amdgcn_exp2f((s[j] - mx) * scale_log2e) : 0.f;   // keys >= F (odd-F partner): weight 0
     sum += s[j];
   }
   const float inv = 1.0f / sum;
+  f16x2 pp[FP];
+#pragma unroll
+  for (int jp = 0; jp < FP; ++jp) pp[jp] = f16x2{(f16)s[2 * jp], (f16)s[2 * jp + 1]};
   f16* op = out + (((int64_t)b * F + i) * T + t) * (int64_t)C + g * CG + h * d;
   for (int c = c0; c < c1; ++c) {
     float acc[8];
 #pragma unroll
     for (int x = 0; x < 8; ++x) acc[x] = 0.f;
 #pragma unroll
-    for (int j = 0; j < FMAX; ++j) {
-      if (j < F) {
-        U4H8 vv;
-        vv.u = *(const u32x4*)(sv + j * CG + h * d + c * 8);
+    for (int jp = 0; jp < FP; ++jp) {
+      if (jp < F2) {
+        const f16* vp = sv + ((int64_t)jp * CG + h * d + c * 8) * 2;
+        union { u32x4 u; f16x2 p[4]; } v0, v1;
+        v0.u = *(const u32x4*)vp;
+        v1.u = *(const u32x4*)(vp + 8);
 #pragma unroll
-        for (int x = 0; x < 8; ++x) acc[x] = fmaf((float)vv.e[x], s[j], acc[x]);
+        for (int x = 0; x < 4; ++x) {
+          acc[x] = __builtin_amdgcn_fdot2(pp[jp], v0.p[x], acc[x], false);
+          acc[4 + x] = __builtin_amdgcn_fdot2(pp[jp], v1.p[x], acc[4 + x], false);
+        }
       }
     }
     U4H8 ov;
@@ -528,7 +582,8 @@ extern "C" int anip_temporal_attention(const void* qkv, void* out, int B, int F,
   for (int c = heads; c >= 1; --c)
     if (heads % c == 0 && c * d <= 320 && c * F <= NT) { hpg = c; break; }
   ANIP_REQUIRE(hpg * F <= NT, "anip_temporal_attention: F=%d too large", F);
-  const size_t lds = (size_t)3 * F * hpg * d * sizeof(f16);
+  const int F2 = (F + 1) / 2;
+  const size_t lds = (size_t)3 * (2 * F2) * hpg * d * sizeof(f16);   // q, k: 2*F2 rows; v: F2 rows of key pairs
   ANIP_REQUIRE(lds <= 65536, "anip_temporal_attention: LDS budget exceeded (F=%d d=%d)", F, d);
   const int64_t blocks = (int64_t)B * T * (heads / hpg);
   ANIP_REQUIRE(blocks < (1ll << 31), "anip_temporal_attention: grid too large");

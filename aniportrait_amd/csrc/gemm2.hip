@@ -210,7 +210,16 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
 #pragma unroll
   for (int kh = 0; kh < KH; ++kh) koff[kh] = ((kh * 4 + fq) ^ swz_of<BKT>(fr)) << 4;
   const int a_row_off = (wm * WTM + fr) * RB;
-  const int b_row_off = (wn * WTN + fr) * RB;
+  // Column (within the block tile) of this wave's j-th 16-column MFMA tile.  Even tile counts: the wave's WTN columns
+  // are contiguous.  Odd counts (BN = 160 / 320: 5 tiles = 80 columns = 160 B per wave): contiguous ranges would put
+  // every second wave at an odd multiple of 80 columns, i.e. all its 64-B row segments (the epilogue pairs two tiles:
+  // 4 lanes x 16 B) 32 B off the 64-B access granule — rocprofv3 WRITE_SIZE 1.5x the output bytes on the N = 960
+  // layer, the residual reads likewise.  Instead each wave takes NB - 1 tiles from a 64-B aligned contiguous range and
+  // its last (single) tile from the tail of the block tile.
+  auto tile_c = [&](int j) -> int {
+    if ((NB & 1) == 0) return wn * WTN + j * 16;
+    return j < NB - 1 ? wn * (NB - 1) * 16 + j * 16 : WNW * (NB - 1) * 16 + wn * 16;
+  };
 
   f32x4 acc[FM][NB];
 #pragma unroll
@@ -227,13 +236,13 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
   const bool rb_uni = acc_has_bias && p.rowbias != nullptr &&
                       (m0 / p.rows_per_group == (m0 + BM2 - 1) / p.rows_per_group);
   if (!TRANS && acc_has_bias) {
-    const int cb = n0 + wn * WTN + (lane >> 4) * 4;          // column of acc[.][0][0] in this lane
     const float* rb_row = rb_uni ? p.rowbias + (int64_t)(m0 / p.rows_per_group) * p.ld_rowbias : nullptr;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
+      const int cb = n0 + tile_c(j) + (lane >> 4) * 4;       // column of acc[.][j][0] in this lane
       f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (p.bias != nullptr) b = *(const f32x4*)(p.bias + cb + j * 16);
-      if (rb_uni) b += *(const f32x4*)(rb_row + cb + j * 16);
+      if (p.bias != nullptr) b = *(const f32x4*)(p.bias + cb);
+      if (rb_uni) b += *(const f32x4*)(rb_row + cb);
 #pragma unroll
       for (int i = 0; i < FM; ++i) acc[i][j] = b;
     }
@@ -271,7 +280,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
       const int ko = kh ? koff[KH - 1] : koff[0];
       f16x8 af[FM], bf[NB];
 #pragma unroll
-      for (int j = 0; j < NB; ++j) bf[j] = *(const f16x8*)(sb + b_row_off + j * 16 * RB + ko);
+      for (int j = 0; j < NB; ++j) bf[j] = *(const f16x8*)(sb + (tile_c(j) + fr) * RB + ko);
 #pragma unroll
       for (int i = 0; i < FM; ++i) af[i] = *(const f16x8*)(sa + a_row_off + i * 16 * RB + ko);
       if (grp == 1 && kh == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -316,7 +325,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
       for (int kh = 0; kh < KH; ++kh) {
         f16x8 bf[NB];
 #pragma unroll
-        for (int t = 0; t < NB; ++t) bf[t] = *(const f16x8*)(sb + b_row_off + t * 16 * RB + koff[kh]);
+        for (int t = 0; t < NB; ++t) bf[t] = *(const f16x8*)(sb + (tile_c(t) + fr) * RB + koff[kh]);
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
           const f16x8 af = *(const f16x8*)(sa + a_row_off + i * 16 * RB + koff[kh]);
@@ -466,12 +475,12 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
     float bt[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {       // all bias loads in front of the first store
-      const int n = n0 + wn * WTN + j * 16 + fr;
+      const int n = n0 + tile_c(j) + fr;
       bt[j] = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
     }
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      const int n = n0 + wn * WTN + j * 16 + fr;
+      const int n = n0 + tile_c(j) + fr;
       const float bn_ = bt[j];
 #pragma unroll
       for (int ip = 0; ip < FM / 2; ++ip) {
@@ -540,7 +549,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
     if (!tight) {
 #pragma unroll
       for (int jp = 0; jp < NB / 2; ++jp) {
-        const int n = n0 + wn * WTN + (2 * jp + tsel) * 16 + csel;
+        const int n = n0 + tile_c(2 * jp) + tsel * 16 + csel;
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
           float v[8];
@@ -555,7 +564,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
         }
       }
       if (NB & 1) {
-        const int n = n0 + wn * WTN + (NB - 1) * 16 + fq * 4;
+        const int n = n0 + tile_c(NB - 1) + fq * 4;
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
           float v[4];
@@ -584,7 +593,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
       const bool rb_row = has_rb && !rb_uni;               // row-group bias that changes inside the block (rare)
 #pragma unroll
       for (int jp = 0; jp < NB / 2; ++jp) {
-        const int n = n0 + wn * WTN + (2 * jp + tsel) * 16 + csel;
+        const int n = n0 + tile_c(2 * jp) + tsel * 16 + csel;
         const uint32_t rn = rrow + (uint32_t)n * 2u, on = orow + (uint32_t)n * esz;
 #pragma unroll
         for (int ib = 0; ib < FM; ib += RBAT) {
@@ -628,7 +637,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
         }
       }
       if (NB & 1) {
-        const int n = n0 + wn * WTN + (NB - 1) * 16 + fq * 4;
+        const int n = n0 + tile_c(NB - 1) + fq * 4;
         const uint32_t rn = rrow + (uint32_t)n * 2u, on = orow + (uint32_t)n * esz;
         union H4 { u32x2 u; f16 e[4]; };
 #pragma unroll
