@@ -42,6 +42,7 @@ SIGNATURES = {
     "anip_last_error": (C.c_char_p, []),
     "anip_device_info": (c_int, [C.c_char_p, c_int, C.POINTER(c_int)]),
     "anip_groupnorm_ws_floats": (c_int64, [c_int, c_int64, c_int, c_int]),
+    "anip_groupnorm_single_launch": (c_int, [c_int, c_int64, c_int, c_int]),
     "anip_groupnorm": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64,
                                c_int, c_float, c_int, c_void_p, c_void_p]),
     "anip_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_int64,

@@ -110,7 +110,13 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs a) {
   const int ko0 = ((0 * 4 + fq) ^ (fr & 7)) << 4, ko1 = ((1 * 4 + fq) ^ (fr & 7)) << 4;
   const int a_row = (wm * 64 + fr) * 128;                      // x / H rows of this wave (+ i * 16 * 128)
   const int b1_row = (wn * 32 + fr) * 128;                     // W1 stage rows: [16 value | 16 gate] of this wave
-  const int b2_row = (wn * (C_ / 4) + fr) * 128;               // W2 rows (output columns) of this wave
+  // output column of this wave's j-th 16-column tile: FN is odd (5 tiles = 80 columns = 160 B), so contiguous ranges
+  // would leave waves 1 and 3 with every 64-B row segment of the epilogue 32 B off the access granule (see gemm2.hip):
+  // four tiles from a 128-B aligned range, the fifth from the tail
+  auto tile_c = [&](int j) -> int {
+    if ((FN & 1) == 0) return wn * (C_ / 4) + j * 16;
+    return j < FN - 1 ? wn * (FN - 1) * 16 + j * 16 : 4 * (FN - 1) * 16 + wn * 16;
+  };
 
   f32x4 oacc[4][FN];
 #pragma unroll
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs a) {
       const int ko = ks ? ko1 : ko0;
       f16x8 bf[FN];
 #pragma unroll
-      for (int j = 0; j < FN; ++j) bf[j] = *(const f16x8*)(w2s + b2_row + j * 16 * 128 + ko);
+      for (int j = 0; j < FN; ++j) bf[j] = *(const f16x8*)(w2s + (tile_c(j) + fr) * 128 + ko);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const f16x8 af = *(const f16x8*)(hs + a_row + i * 16 * 128 + ko);
@@ -190,11 +196,29 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs a) {
 
   // ---- epilogue: oacc[i][j][r] = out[m0 + wm*64 + i*16 + fr][wn*(C_/4) + j*16 + fq*4 + r] ---------------------------
   const int tsel = fq & 1, csel = (fq >> 1) * 8;
+  // residual vectors of a column pair in flight together AHEAD of its stores (a load written after a store stays after
+  // it: `out` may alias anything as far as the compiler knows — see gemm2.hip)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + fr;
+  for (int jp = 0; jp < FN / 2; ++jp) {
+    const int n = tile_c(2 * jp) + tsel * 16 + csel;
+    U4H8 res[4];
+    float add[8];
 #pragma unroll
-    for (int jp = 0; jp < FN / 2; ++jp) {
+    for (int e = 0; e < 8; ++e) add[e] = 0.f;
+    if (a.b2 != nullptr) {
+      const float4 b0 = *(const float4*)(a.b2 + n), b1 = *(const float4*)(a.b2 + n + 4);
+      add[0] = b0.x; add[1] = b0.y; add[2] = b0.z; add[3] = b0.w;
+      add[4] = b1.x; add[5] = b1.y; add[6] = b1.z; add[7] = b1.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + fr;
+      res[i].u = u32x4{0u, 0u, 0u, 0u};
+      if (a.res != nullptr && m < a.M) res[i].u = *(const u32x4*)(a.res + (int64_t)m * C_ + n);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + fr;
       float v[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -203,38 +227,33 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs a) {
         v[r] = x;
         v[4 + r] = y;
       }
-      const int n = wn * (C_ / 4) + (2 * jp + tsel) * 16 + csel;
       if (m < a.M) {
-        if (a.b2 != nullptr) {
-          const float4 b0 = *(const float4*)(a.b2 + n), b1 = *(const float4*)(a.b2 + n + 4);
-          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-          v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-        }
         U4H8 t;
-        if (a.res != nullptr) {
-          t.u = *(const u32x4*)(a.res + (int64_t)m * C_ + n);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] += (float)t.e[e];
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) t.e[e] = (f16)v[e];
+        for (int e = 0; e < 8; ++e) t.e[e] = (f16)((v[e] + add[e]) + (float)res[i].e[e]);
         *(u32x4*)(a.out + (int64_t)m * C_ + n) = t.u;
       }
     }
-    if (FN & 1) {
-      const int n = wn * (C_ / 4) + (FN - 1) * 16 + fq * 4;
+  }
+  if (FN & 1) {
+    const int n = tile_c(FN - 1) + fq * 4;
+    union H4u { u32x2 u; f16 e[4]; };
+    H4u res[4];
+    f32x4 add = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.b2 != nullptr) add = *(const f32x4*)(a.b2 + n);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + fr;
+      res[i].u = u32x2{0u, 0u};
+      if (a.res != nullptr && m < a.M) res[i].u = *(const u32x2*)(a.res + (int64_t)m * C_ + n);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + fr;
       if (m < a.M) {
-        float v[4];
+        H4u t;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = oacc[i][FN - 1][r] + (a.b2 != nullptr ? a.b2[n + r] : 0.f);
-        union { u32x2 u; f16 e[4]; } t;
-        if (a.res != nullptr) {
-          t.u = *(const u32x2*)(a.res + (int64_t)m * C_ + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)t.e[e];
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) t.e[e] = (f16)v[e];
+        for (int e = 0; e < 4; ++e) t.e[e] = (f16)((oacc[i][FN - 1][e] + add[e]) + (float)res[i].e[e]);
         *(u32x2*)(a.out + (int64_t)m * C_ + n) = t.u;
       }
     }

@@ -371,6 +371,18 @@ extern "C" int64_t anip_groupnorm_ws_floats(int N, int64_t HW, int C, int G) {
   return (int64_t)N * nchunks * G * 2;
 }
 
+// 1 if anip_groupnorm runs this problem as ONE kernel (gn_slab_kernel), 0 if as statistics + apply.
+// Single-launch form for the 8x8 / 16x16 levels (measured on MI355X, 32 frames, stats + apply vs one slab kernel:
+// 16x16 C1280 27.8 -> 18.7 us, C2560 46.7 -> 31.5, 8x8 C1280 19.3 -> 14.6, C2560 29.9 -> 15.6; from 32x32 up the slab's
+// narrow row segments (cpg * 2 = 20 .. 120 B) lose to the two coalesced passes: 64x64 C320 57 -> 147 us).
+// ANIP_GN_SLAB_HW overrides the row limit (0 disables).
+extern "C" int anip_groupnorm_single_launch(int N, int64_t HW, int C, int G) {
+  static const int slab_hw = getenv("ANIP_GN_SLAB_HW") ? atoi(getenv("ANIP_GN_SLAB_HW")) : 256;
+  if (G <= 0 || C % G != 0) return 0;
+  const int cpg = C / G;
+  return (slab_hw > 0 && HW <= slab_hw && cpg <= 256 && (cpg & 1) == 0 && (int64_t)N * G >= 256) ? 1 : 0;
+}
+
 extern "C" int anip_groupnorm(const void* x1, int C1, const void* x2, int C2, const float* gamma, const float* beta,
                               void* y, int N, int64_t HW, int G, float eps, int silu, float* ws, void* stream) {
   const int C = C1 + C2;
@@ -379,14 +391,9 @@ extern "C" int anip_groupnorm(const void* x1, int C1, const void* x2, int C2, co
   ANIP_REQUIRE((C1 & 7) == 0 && (C2 & 7) == 0 && C % G == 0, "anip_groupnorm: C1=%d C2=%d must be multiples of 8, C %% G == 0", C1, C2);
   ANIP_REQUIRE((C2 == 0) == (x2 == nullptr), "anip_groupnorm: x2/C2 mismatch");
   ANIP_REQUIRE(C <= 8192, "anip_groupnorm: C=%d too large", C);
-  // single-launch form for the 8x8 / 16x16 levels (measured on MI355X, 32 frames, stats + apply vs one slab kernel:
-  // 16x16 C1280 27.8 -> 18.7 us, C2560 46.7 -> 31.5, 8x8 C1280 19.3 -> 14.6, C2560 29.9 -> 15.6; from 32x32 up the
-  // slab's narrow row segments (cpg * 2 = 20 .. 120 B) lose to the two coalesced passes: 64x64 C320 57 -> 147 us).
-  // ANIP_GN_SLAB_HW overrides the row limit (0 disables).
   {
-    static const int slab_hw = getenv("ANIP_GN_SLAB_HW") ? atoi(getenv("ANIP_GN_SLAB_HW")) : 256;
-    const int cpg = C / G;
-    if (slab_hw > 0 && HW <= slab_hw && cpg <= 256 && (cpg & 1) == 0 && (int64_t)N * G >= 256) {
+    if (anip_groupnorm_single_launch(N, HW, C, G)) {
+      const int cpg = C / G;
       const int V = ((cpg & 7) == 0) ? 8 : ((cpg & 3) == 0) ? 4 : 2;
       AnipProfScope prof_(ANIP_K_GN_APPLY, (void*)stream);
       const dim3 grid((unsigned)(N * G));

@@ -199,8 +199,12 @@ def groupnorm(x1, gamma, beta, groups, eps, silu, x2=None):
     Ctot = C1 + C2
     y = torch.empty((N, HW, Ctot), dtype=F16, device=x1.device)
     ws = torch.empty((lib.anip_groupnorm_ws_floats(N, HW, Ctot, groups),), dtype=F32, device=x1.device)
-    _work(K_GN_STATS, N * HW * Ctot * 2, f"N{N} HW{HW} C{Ctot}")
-    _work(K_GN_APPLY, N * HW * Ctot * 4, f"N{N} HW{HW} C{Ctot} silu{int(bool(silu))}")
+    if _WORK is not None:
+        if lib.anip_groupnorm_single_launch(N, HW, Ctot, groups):
+            _work(K_GN_APPLY, N * HW * Ctot * 4, f"N{N} HW{HW} C{Ctot} silu{int(bool(silu))} slab")
+        else:
+            _work(K_GN_STATS, N * HW * Ctot * 2, f"N{N} HW{HW} C{Ctot}")
+            _work(K_GN_APPLY, N * HW * Ctot * 4, f"N{N} HW{HW} C{Ctot} silu{int(bool(silu))}")
     L.check(lib.anip_groupnorm(_p(x1), C1, _p(x2), C2, _p(_req(gamma, F32, "gamma")), _p(_req(beta, F32, "beta")),
                                _p(y), N, HW, groups, float(eps), int(bool(silu)), _p(ws), _stream()),
             "anip_groupnorm")

@@ -40,6 +40,9 @@ int anip_device_info(char* arch, int arch_len, int* num_cu);
  * src/models/unet_3d_blocks.py:697,826 into the norm).  y [N,HW,C1+C2] fp16.
  * ws: fp32 workspace of anip_groupnorm_ws_floats(N,HW,C,G) elements. */
 int64_t anip_groupnorm_ws_floats(int N, int64_t HW, int C, int G);
+/* 1 if anip_groupnorm runs (N, HW, C, G) as a single kernel launch (one block per (image, group) slab: the 8x8 / 16x16
+ * levels), 0 if as a statistics pass + an apply pass; only of interest to per-kernel profilers (bench.py). */
+int anip_groupnorm_single_launch(int N, int64_t HW, int C, int G);
 int anip_groupnorm(const void* x1, int C1, const void* x2, int C2, const float* gamma, const float* beta,
                    void* y, int N, int64_t HW, int G, float eps, int silu, float* ws, void* stream);
 

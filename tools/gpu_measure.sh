@@ -25,13 +25,13 @@ if [[ $WHAT == all || $WHAT == *rocprof* ]]; then
   find $OUT/prof -name "*stats*" | head -3
 fi
 if [[ $WHAT == all || $WHAT == *pmc* ]]; then
-  echo "== PMC: HBM traffic of the bench command (no graphs: counters cannot follow graph replays)"
+  echo "== PMC: HBM traffic of the denoising step (eager UNet3D forward at the C2 shapes; see tools/pmc_unet_step.py)"
   for CTR in FETCH_SIZE WRITE_SIZE; do
-    ( cd /tmp && ANIP_NO_GRAPH=1 timeout 600 rocprofv3 --pmc $CTR --kernel-trace -T -f csv -d $OUT/pmc_bench/$CTR -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $OUT/pmc_bench_$CTR.log 2>&1; echo "pmc $CTR rc=$?" )
+    ( cd /tmp && timeout 600 rocprofv3 --pmc $CTR --kernel-trace -T -f csv -d $OUT/pmc_step/$CTR -o p -- python $GRAFT_REPO_ROOT/tools/pmc_unet_step.py 2 > $OUT/pmc_step_$CTR.log 2>&1; echo "pmc $CTR rc=$?" )
   done
-  find $OUT/pmc_bench -name "*kernel_trace*" -delete 2>/dev/null
-  python tools/pmc_summarize.py $OUT/pmc_bench $OUT/pmc_bench_summary.json --families 2>&1 | tail -n 1
-  find $OUT/pmc_bench -name "*counter_collection*" -size +6M -delete 2>/dev/null
+  find $OUT/pmc_step -name "*kernel_trace*" -delete 2>/dev/null
+  python tools/pmc_summarize.py $OUT/pmc_step $OUT/pmc_step_summary.json --families 2>&1 | tail -n 1
+  find $OUT/pmc_step -name "*counter_collection*" -size +6M -delete 2>/dev/null
   echo "== PMC: SQ / TCC counters on the kernel set"
   i=0
   for CTRS in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
