@@ -9,7 +9,7 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "lib", "libaniportrait_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -33,6 +33,7 @@ class GemmParams(C.Structure):
         ("Hout", c_int), ("Wout", c_int), ("stride", c_int), ("pad", c_int), ("upsample", c_int),
         ("trans_out", c_int),
         ("workspace", c_void_p), ("workspace_bytes", c_int64),
+        ("head_dim", c_int),
     ]
 
 
@@ -60,7 +61,7 @@ SIGNATURES = {
                                c_int, c_void_p, c_void_p]),
     "anip_ref_attention": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                    c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int,
-                                   c_float, c_void_p]),
+                                   c_float, c_int64, c_int64, c_void_p]),
     "anip_temporal_attention": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "anip_softmax_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "anip_linear_small": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -26,6 +26,7 @@ struct RefAttnArgs {
   const f16* k; int64_t ldk;
   const f16* vt; int64_t ldvt;
   const f16* kref; int64_t ldkr;
+  int64_t k_hs, kr_hs;   // elements between two heads' K data (token-major: d; head-major: tokens * d)
   const f16* vtref; int64_t ldvtr;
   const int* ref_index;
   f16* out; int64_t ldo;
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(NT, (D > 96 ? 1 : 2)) void ref_attn_kernel(const Re
     const int64_t ldk = second ? a.ldkr : a.ldk;
     const int64_t ldv = second ? a.ldvtr : a.ldvt;
     const int64_t tok0 = (int64_t)(second ? ref : n) * T + (int64_t)tt * KV;
-    const f16* kb = (second ? a.kref : a.k) + tok0 * ldk + h * D;
+    const f16* kb = (second ? a.kref : a.k) + tok0 * ldk + h * (second ? a.kr_hs : a.k_hs);
     const f16* vb = (second ? a.vtref : a.vt) + (int64_t)h * D * ldv + tok0;
     if (FAST) {
 #pragma unroll
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(NT) void temporal_attn_kernel(const f16* __restrict
 extern "C" int anip_ref_attention(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt,
                                   int64_t ldvt, const void* kref, int64_t ldkr, const void* vtref, int64_t ldvtr,
                                   const int* ref_index, void* out, int64_t ldo, int Nf, int T, int heads, int d,
-                                  float scale, void* stream) {
+                                  float scale, int64_t k_head_stride, int64_t kref_head_stride, void* stream) {
   ANIP_REQUIRE(q && k && vt && out, "anip_ref_attention: null pointer");
   ANIP_REQUIRE(Nf > 0 && T > 0 && heads > 0, "anip_ref_attention: bad sizes");
   ANIP_REQUIRE((ldq & 7) == 0 && (ldk & 7) == 0 && (ldo & 3) == 0, "anip_ref_attention: ldq/ldk %% 8, ldo %% 4 required");
@@ -546,6 +547,8 @@ extern "C" int anip_ref_attention(const void* q, int64_t ldq, const void* k, int
   a.k = (const f16*)k; a.ldk = ldk;
   a.vt = (const f16*)vt; a.ldvt = ldvt;
   a.kref = (const f16*)kref; a.ldkr = ldkr;
+  a.k_hs = k_head_stride > 0 ? k_head_stride : d;
+  a.kr_hs = kref_head_stride > 0 ? kref_head_stride : d;
   a.vtref = (const f16*)vtref; a.ldvtr = ldvtr;
   a.ref_index = ref_index;
   a.out = (f16*)out; a.ldo = ldo;

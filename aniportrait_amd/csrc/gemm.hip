@@ -267,7 +267,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_small_kernel(const anip_gemm
           if (e < nvalid) op[(int64_t)e * p.ldo] = (f16)v[e];
         continue;
       }
-      const int64_t o = obatch + (int64_t)m * p.ldo + ncol;
+      const int64_t o = p.head_dim > 0 ? ((int64_t)(ncol / p.head_dim) * p.M + m) * p.head_dim + ncol % p.head_dim
+                                       : obatch + (int64_t)m * p.ldo + ncol;
+      const int64_t ldo_eff = p.head_dim > 0 ? p.head_dim : p.ldo;
       if (p.out_f32) {
         float* op = (float*)p.out + o;
         if (nvalid == 8 && ((p.ldo & 3) == 0)) {
@@ -280,7 +282,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_small_kernel(const anip_gemm
         }
       } else {
         f16* op = (f16*)p.out + o;
-        if (nvalid == 8 && ((p.ldo & 7) == 0)) {
+        if (nvalid == 8 && ((ldo_eff & 7) == 0)) {
           U4H8 t;
 #pragma unroll
           for (int e = 0; e < 8; ++e) t.e[e] = (f16)v[e];
@@ -340,6 +342,11 @@ extern "C" int anip_gemm(const anip_gemm_params* pp, void* stream) {
   if (p.trans_out)
     ANIP_REQUIRE(p.act == 0 && !p.out_f32 && !p.rowbias && !p.residual && p.batch == 1,
                  "anip_gemm: trans_out supports bias only");
+  if (p.head_dim != 0)
+    ANIP_REQUIRE(p.head_dim > 0 && (p.head_dim & 7) == 0 && p.N % p.head_dim == 0 && !p.trans_out && !p.out_f32 && p.act == 0 &&
+                     p.batch == 1 && !p.conv,
+                 "anip_gemm: head-major output needs head_dim %% 8 == 0, N %% head_dim == 0, fp16, plain epilogue (head_dim=%d N=%d)",
+                 p.head_dim, p.N);
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   dim3 grid((unsigned)(nbm * nbn), (unsigned)p.batch, 1);
   {

@@ -396,7 +396,9 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
           if (e < nvalid) v[e] += (float)rp[e];
       }
     }
-    const int64_t o = obatch + (int64_t)m * p.ldo + n;
+    const int64_t o = p.head_dim > 0 ? ((int64_t)(n / p.head_dim) * p.M + m) * p.head_dim + n % p.head_dim
+                                     : obatch + (int64_t)m * p.ldo + n;
+    const int64_t ldo_eff = p.head_dim > 0 ? p.head_dim : p.ldo;
     if (p.out_f32) {
       float* op = (float*)p.out + o;
       if (nvalid == 8 && ((p.ldo & 3) == 0)) {
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
       }
     } else {
       f16* op = (f16*)p.out + o;
-      if (nvalid == 8 && ((p.ldo & 7) == 0)) {
+      if (nvalid == 8 && ((ldo_eff & 7) == 0)) {
         U4H8 t;
 #pragma unroll
         for (int e = 0; e < 8; ++e) t.e[e] = (f16)v[e];
@@ -446,7 +448,9 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
           if (e < nvalid) v[e] += (float)rp[e];
       }
     }
-    const int64_t o = obatch + (int64_t)m * p.ldo + n;
+    const int64_t o = p.head_dim > 0 ? ((int64_t)(n / p.head_dim) * p.M + m) * p.head_dim + n % p.head_dim
+                                     : obatch + (int64_t)m * p.ldo + n;
+    const int64_t ldo_eff = p.head_dim > 0 ? p.head_dim : p.ldo;
     if (p.out_f32) {
       float* op = (float*)p.out + o;
       if (nvalid == 4 && ((p.ldo & 3) == 0)) *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
@@ -457,7 +461,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
       }
     } else {
       f16* op = (f16*)p.out + o;
-      if (nvalid == 4 && ((p.ldo & 3) == 0)) {
+      if (nvalid == 4 && ((ldo_eff & 3) == 0)) {
         union { u32x2 u; f16 e[4]; } t;
 #pragma unroll
         for (int e = 0; e < 4; ++e) t.e[e] = (f16)v[e];
@@ -543,7 +547,8 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
     // path) takes the tight epilogue below; ragged tiles take the general per-element-guarded one.
     const bool has_rb = p.rowbias != nullptr, has_res = p.residual != nullptr;
     const bool tight = !(dbg & 8) && p.alpha == 1.0f && m0 + BM2 <= p.M && n0 + BN <= p.N &&
-                       (p.out_f32 ? (p.ldo & 3) == 0 : (p.ldo & 7) == 0) && (!has_res || (p.ldr & 7) == 0) &&
+                       (p.out_f32 ? (p.ldo & 3) == 0 : ((p.head_dim > 0 ? p.head_dim : p.ldo) & 7) == 0) &&
+                       (!has_res || (p.ldr & 7) == 0) &&
                        (acc_has_bias || (p.bias == nullptr && !has_rb)) &&
                        (int64_t)p.M * p.ldo * 4 < (1ll << 32) && (!has_res || (int64_t)p.M * p.ldr * 2 < (1ll << 32));
     if (!tight) {
@@ -586,7 +591,8 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
       // accumulators
       const int mrow = m0 + wm * WTM + fr;                 // row of acc[0][.]; tile i is 16 rows further down
       const uint32_t esz = p.out_f32 ? 4u : 2u;
-      const uint32_t ldr_b = (uint32_t)p.ldr * 2u, ldo_b = (uint32_t)p.ldo * esz;
+      const bool hm = p.head_dim > 0;      // head-major output: row step = head_dim, plus a per-column head offset
+      const uint32_t ldr_b = (uint32_t)p.ldr * 2u, ldo_b = (uint32_t)(hm ? p.head_dim : p.ldo) * esz;
       const char* resb = (const char*)p.residual;
       char* outb = (char*)p.out + obatch * (int64_t)esz;
       const uint32_t rrow = (uint32_t)mrow * ldr_b, orow = (uint32_t)mrow * ldo_b;
@@ -594,7 +600,9 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
 #pragma unroll
       for (int jp = 0; jp < NB / 2; ++jp) {
         const int n = n0 + tile_c(2 * jp) + tsel * 16 + csel;
-        const uint32_t rn = rrow + (uint32_t)n * 2u, on = orow + (uint32_t)n * esz;
+        const uint32_t rn = rrow + (uint32_t)n * 2u;
+        const uint32_t on = orow + (hm ? ((uint32_t)(n / p.head_dim) * (uint32_t)p.M * (uint32_t)p.head_dim +
+                                          (uint32_t)(n % p.head_dim)) : (uint32_t)n) * esz;
 #pragma unroll
         for (int ib = 0; ib < FM; ib += RBAT) {
           U4H8 res[RBAT];
@@ -638,7 +646,9 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
       }
       if (NB & 1) {
         const int n = n0 + tile_c(NB - 1) + fq * 4;
-        const uint32_t rn = rrow + (uint32_t)n * 2u, on = orow + (uint32_t)n * esz;
+        const uint32_t rn = rrow + (uint32_t)n * 2u;
+        const uint32_t on = orow + (hm ? ((uint32_t)(n / p.head_dim) * (uint32_t)p.M * (uint32_t)p.head_dim +
+                                          (uint32_t)(n % p.head_dim)) : (uint32_t)n) * esz;
         union H4 { u32x2 u; f16 e[4]; };
 #pragma unroll
         for (int ib = 0; ib < FM; ib += RBAT) {
@@ -736,8 +746,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 #pragma unroll
       for (int e = 0; e < 4; ++e) op[e] = v[e];
     } else {
-      f16* op = (f16*)p.out + (int64_t)m * p.ldo + n;
-      if ((p.ldo & 3) == 0 && (((uintptr_t)p.out) & 7) == 0) {
+      f16* op = (f16*)p.out + (p.head_dim > 0 ? ((int64_t)(n / p.head_dim) * p.M + m) * p.head_dim + n % p.head_dim
+                                              : (int64_t)m * p.ldo + n);
+      if (((p.head_dim > 0 ? p.head_dim : p.ldo) & 3) == 0 && (((uintptr_t)p.out) & 7) == 0) {
         union { u32x2 u; f16 e[4]; } t;
 #pragma unroll
         for (int e = 0; e < 4; ++e) t.e[e] = (f16)v[e];

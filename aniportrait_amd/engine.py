@@ -226,16 +226,16 @@ class RefState:
         self.pool = {}
 
 
-def project_reference_bank(net, p, ref):
+def project_reference_bank(net, p, ref, d):
     """K_ref = to_k(bank), V_ref^T = to_v(bank)^T of one hooked block (transformer-block path p), written IN PLACE into
     the block's per-shape buffers (src/models/mutual_self_attention.py:147-165 does this projection for every frame of
-    every step; the bank is constant over a clip)."""
+    every step; the bank is constant over a clip).  d = head dim: K_ref is stored head-major."""
     C = ref.bank.shape[-1]
     bank2 = ref.bank.reshape(-1, C)
     if bank2.dtype != F16 or bank2.device != net.device:
         bank2 = bank2.to(net.device, F16)
     kbuf, vbuf = ref.buffers(bank2.shape[0], C, net.device)
-    ref.kref = ops.gemm(bank2, net.lin(p + ".attn1.to_k.weight"), out=kbuf)
+    ref.kref = ops.gemm(bank2, net.lin(p + ".attn1.to_k.weight"), out=kbuf, head_dim=d)   # head-major, like the frame's own K
     ref.vtref = ops.gemm(bank2, net.lin(p + ".attn1.to_v.weight"), trans_out=True, out=vbuf)
     ref.stale = False
 
@@ -248,7 +248,7 @@ def prepare_reference(net, cfg, refs, ehs, attn2_cache):
     for p in attention_paths(cfg):
         ref = refs.get(p)
         if ref is not None and ref.mode == "read" and ref.bank is not None and (ref.kref is None or ref.stale):
-            project_reference_bank(net, p + ".transformer_blocks.0", ref)
+            project_reference_bank(net, p + ".transformer_blocks.0", ref, ref.bank.shape[-1] // cfg["attention_head_dim"])
     attn2_cache.get(net, cfg, ehs, refresh=True)
 
 
@@ -263,20 +263,21 @@ def transformer_block(net, p, h, Nf, T, heads, attn2_vec, rows_per_sample, ref=N
         ref.written = nh.reshape(Nf, T, C)
         if stop_after_bank:
             return None
-    # Q and K as separate matrices: with the fused [to_q; to_k] projection every head's K row (2 d bytes) sits at a
-    # 4C-byte stride and the attention kernel's K-tile reads touch twice the cache lines (measured at 64x64, d = 40:
-    # 1.75 ms fused rows vs 1.60 ms separate, against +12 us for the second GEMM launch)
+    # Q token-major; K HEAD-MAJOR (heads, tokens, d): with a fused [to_q; to_k] projection every head's K row (2 d
+    # bytes) sits at a 4C-byte stride and the attention kernel's K-tile reads touch 2-3x the cache lines; head-major, a
+    # 64-key tile of a head is one contiguous run (measured at 64x64, d = 40: 1.75 ms fused rows, 1.60 ms separate
+    # matrices, 1.54 ms contiguous rows — against +12 us for the second GEMM launch)
     q = ops.gemm(nh, net.lin(p + ".attn1.to_q.weight"))
-    k = ops.gemm(nh, net.lin(p + ".attn1.to_k.weight"))
+    k = ops.gemm(nh, net.lin(p + ".attn1.to_k.weight"), head_dim=d)
     vt = ops.gemm(nh, net.lin(p + ".attn1.to_v.weight"), trans_out=True)  # V^T [C][Nf*T]
     kw = {}
     if mode == "read" and ref.bank is not None:
         if ref.kref is None or ref.stale:
-            project_reference_bank(net, p, ref)
+            project_reference_bank(net, p, ref, d)
         assert ref.bank.shape[1] == T, "reference bank token count differs from the denoising latents"
-        kw = dict(kref=ref.kref, ldkr=C, vtref=ref.vtref, ldvtr=ref.vtref.shape[1], ref_index=ref_index[0],
-                  n_ref_frames=ref_index[1])
-    a = ops.ref_attention(q, C, k, C, vt, vt.shape[1], Nf, T, heads, d, **kw)
+        kw = dict(kref=ref.kref, ldkr=d, kref_head_stride=ref.kref.shape[0] * d, vtref=ref.vtref,
+                  ldvtr=ref.vtref.shape[1], ref_index=ref_index[0], n_ref_frames=ref_index[1])
+    a = ops.ref_attention(q, C, k, d, vt, vt.shape[1], Nf, T, heads, d, k_head_stride=Nf * T * d, **kw)
     # attn1 out-proj + residual (+ the collapsed attn2: one vector per sample)
     h = ops.gemm(a, net.lin(p + ".attn1.to_out.0.weight"), net.f32(p + ".attn1.to_out.0.bias"),
                  rowbias=attn2_vec, rows_per_group=rows_per_sample, residual=h)

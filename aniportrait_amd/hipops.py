@@ -223,7 +223,7 @@ def layernorm(x, gamma, beta, eps=1e-5, pe=None, rows_per_frame=0, frames=0):
 
 
 def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None, act=0, out_f32=False,
-         alpha=1.0, out=None, conv=None, batch=1, ldo=None, ldr=None, trans_out=False):
+         alpha=1.0, out=None, conv=None, batch=1, ldo=None, ldr=None, trans_out=False, head_dim=0):
     """out = epilogue(alpha * A @ W^T).
 
     A (M, K) fp16 [+ A2 (M, K2): K split over two sources]; W (N, K) fp16; bias (N,) fp32;
@@ -233,6 +233,7 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
     conv: dict(Nimg, Hin, Win, Cin, Hout, Wout, stride, pad, upsample) -> A is the NHWC image batch.
     batch > 1: A (B, M, K) or (M, K) shared; W (B, N, K) or (N, K) shared -> out (B, M, N).
     trans_out: return the transposed result (N, M) (bias only, fp16).
+    head_dim > 0: head-major result (N / head_dim, M, head_dim): each head's rows contiguous (K of ref_attention).
     """
     lib = L.load()
     p = L.GemmParams()
@@ -281,6 +282,12 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
             out = torch.empty((N, M), dtype=F16, device=A.device)
         p.trans_out = 1
         ldo = M if ldo is None else ldo
+    if head_dim:
+        assert not batched and conv is None and act == 0 and not out_f32 and not trans_out and N % head_dim == 0
+        if out is None:
+            out = torch.empty((N // head_dim, M, head_dim), dtype=F16, device=A.device)
+        assert out.numel() == M * N and out.is_contiguous()
+        p.head_dim = int(head_dim)
     if out is None:
         shape = (batch, M, n_out) if batched else (M, n_out)
         out = torch.empty(shape, dtype=F32 if out_f32 else F16, device=A.device)
@@ -304,7 +311,8 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
         else:
             desc = (f"M{M} N{N} K{K}{' b%d' % batch if batched else ''}{' geglu' if act == 1 else ''}"
                     f"{' A2' if A2 is not None else ''}{' rb' if rowbias is not None else ''}"
-                    f"{' res' if residual is not None else ''}{' T' if trans_out else ''}{' f32' if out_f32 else ''}")
+                    f"{' res' if residual is not None else ''}{' T' if trans_out else ''}{' f32' if out_f32 else ''}"
+                    f"{' hm' if head_dim else ''}")
         _work(K_CONV3X3 if conv is not None else K_GEMM, 2 * M * N * K * max(1, int(p.batch)), desc)
     if M <= 16384:   # few output tiles: the library may want fp32 scratch for split-K
         wsb = lib.anip_gemm_workspace_bytes(C.byref(p))
@@ -406,9 +414,10 @@ def batchnorm(x, gamma, beta, running_mean=None, running_var=None, eps=1e-5, rel
 
 
 def ref_attention(q, ldq, k, ldk, vt, ldvt, n_frames, T, heads, d, kref=None, ldkr=0, vtref=None, ldvtr=0,
-                  ref_index=None, scale=None, n_ref_frames=0):
+                  ref_index=None, scale=None, n_ref_frames=0, k_head_stride=0, kref_head_stride=0):
     """see anip_ref_attention; returns (n_frames*T, heads*d) fp16.  `n_ref_frames` (frames whose
-    ref_index >= 0) is only used for the profiler's FLOP count."""
+    ref_index >= 0) is only used for the profiler's FLOP count.  k / kref head-major (gemm(head_dim=d) output, shape
+    (heads, tokens, d)): ldk = d and k_head_stride = tokens * d."""
     lib = L.load()
     _work(K_REF_ATTN, 4 * T * T * heads * d * (n_frames + (n_ref_frames if ref_index is not None else 0)),
           f"Nf{n_frames} T{T} h{heads} d{d} ref{n_ref_frames if ref_index is not None else 0}")
@@ -416,7 +425,8 @@ def ref_attention(q, ldq, k, ldk, vt, ldvt, n_frames, T, heads, d, kref=None, ld
     if scale is None:
         scale = d ** -0.5
     L.check(lib.anip_ref_attention(_p(q), ldq, _p(k), ldk, _p(vt), ldvt, _p(kref), ldkr, _p(vtref), ldvtr,
-                                   _p(ref_index), _p(out), heads * d, n_frames, T, heads, d, float(scale), _stream()),
+                                   _p(ref_index), _p(out), heads * d, n_frames, T, heads, d, float(scale),
+                                   int(k_head_stride), int(kref_head_stride), _stream()),
             "anip_ref_attention")
     return out
 

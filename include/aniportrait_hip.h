@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ANIP_ABI_VERSION 8
+#define ANIP_ABI_VERSION 9
 
 int anip_version(void);
 const char* anip_last_error(void);
@@ -88,6 +88,11 @@ typedef struct anip_gemm_params {
    * `workspace` (fp32 partial tiles [split][M][N], reduced with the whole epilogue by a second kernel);
    * 0 means no workspace is needed.  The library never allocates. */
   void* workspace; int64_t workspace_bytes;
+  /* head_dim > 0: head-major output — column n of row m goes to out[(n / head_dim) * M * head_dim + m * head_dim +
+   * n % head_dim] (fp16, non-transposed, batch 1, head_dim % 8 == 0): each head's [M][head_dim] block is contiguous.
+   * The K projection of anip_ref_attention (to_k of src/models/mutual_self_attention.py:147-165): a 64-key tile of one
+   * head is then one contiguous run instead of 2 d-byte pieces at a C-byte stride. */
+  int head_dim;
 } anip_gemm_params;
 int64_t anip_gemm_workspace_bytes(const anip_gemm_params* p);
 int anip_gemm(const anip_gemm_params* p, void* stream);
@@ -133,11 +138,13 @@ int anip_batchnorm(const void* x, const float* gamma, const float* beta, const f
  * For frame n, head h: O = softmax(Q K^T / sqrt(d)) V with keys = [self tokens of frame n]
  * ++ [reference tokens of sample ref_index[n]] (ref_index[n] < 0: self only, the CFG-unconditional
  * frames).  q,k: [Nf*T][ld] fp16 with head h at column h*d; vt: V transposed [heads*d][ldvt] with
- * token (n*T + t) at column n*T+t; kref [Nref*T][ldkr], vtref [heads*d][ldvtr]; out [Nf*T][ldo]. */
+ * token (n*T + t) at column n*T+t; kref [Nref*T][ldkr], vtref [heads*d][ldvtr]; out [Nf*T][ldo].  * k_head_stride / kref_head_stride (elements; 0 = d): distance between two heads' K data.  Token-major K (a column
+ * slice of a [tokens][heads*d] matrix): d, with ldk = the row stride.  Head-major K (anip_gemm head_dim = d output):
+ * tokens_total * d, with ldk = d — a 64-key tile of a head is then one contiguous 128 d-byte run. */
 int anip_ref_attention(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
                        const void* kref, int64_t ldkr, const void* vtref, int64_t ldvtr,
                        const int* ref_index, void* out, int64_t ldo,
-                       int Nf, int T, int heads, int d, float scale, void* stream);
+                       int Nf, int T, int heads, int d, float scale, int64_t k_head_stride, int64_t kref_head_stride, void* stream);
 
 /* ---- temporal self-attention ------------------------------------------------------------------
  * replaces VersatileAttention (src/models/motion_module.py:351-388): for every (b, pixel t, head):

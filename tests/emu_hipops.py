@@ -39,7 +39,7 @@ def _geglu_unpack(y):
 
 
 def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None, act=0, out_f32=False,
-         alpha=1.0, out=None, conv=None, batch=1, ldo=None, ldr=None, trans_out=False):
+         alpha=1.0, out=None, conv=None, batch=1, ldo=None, ldr=None, trans_out=False, head_dim=0):
     assert A.dtype == F16 and W.dtype == F16
     if A.dim() == 3 or W.dim() == 3:
         y = alpha * torch.matmul(A.float(), W.float().transpose(-1, -2))
@@ -77,9 +77,11 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
         y = y + residual.float().reshape(M, -1)
     if trans_out:
         y = y.t()
+    if head_dim:
+        y = y.reshape(M, N // head_dim, head_dim).permute(1, 0, 2)
     y = y.contiguous() if out_f32 else y.to(F16).contiguous()
     if out is not None:
-        out.copy_(y)
+        out.copy_(y.reshape(out.shape))
         return out
     return y
 
@@ -139,10 +141,14 @@ def batchnorm(x, gamma, beta, running_mean=None, running_var=None, eps=1e-5, rel
 
 
 def ref_attention(q, ldq, k, ldk, vt, ldvt, n_frames, T, heads, d, kref=None, ldkr=0, vtref=None, ldvtr=0,
-                  ref_index=None, scale=None, n_ref_frames=0):
+                  ref_index=None, scale=None, n_ref_frames=0, k_head_stride=0, kref_head_stride=0):
     C = heads * d
     scale = d ** -0.5 if scale is None else scale
     Q = q[:, :C].float().reshape(n_frames, T, heads, d).permute(0, 2, 1, 3)
+    if k_head_stride:       # head-major (heads, tokens, d)
+        k = k.reshape(heads, -1, d).permute(1, 0, 2).reshape(-1, C)
+    if kref is not None and kref_head_stride:
+        kref = kref.reshape(heads, -1, d).permute(1, 0, 2).reshape(-1, C)
     K = k[:, :C].float().reshape(n_frames, T, heads, d).permute(0, 2, 1, 3)
     V = vt.float().t().reshape(n_frames, T, heads, d).permute(0, 2, 1, 3)
     out = torch.empty((n_frames, T, C), dtype=F32)

@@ -334,6 +334,39 @@ def test_ref_attention_peaky_with_reference(d, T):
     close(out, torch.cat(refs, 0), f"ref_attention peaky d={d} T={T}", rtol=6e-3, arms=6e-3)
 
 
+@pytest.mark.parametrize("M,N,K,hd", [(32768, 320, 320, 40), (8192, 640, 640, 80), (2048, 1280, 1280, 160), (100, 320, 64, 40),
+                                      (16384, 1408, 1408, 88), (33003, 320, 136, 40)])
+def test_gemm_head_major_output(M, N, K, hd):
+    """anip_gemm head_dim: out[(n / hd)][m][n % hd] — every kernel family behind anip_gemm (wide / narrow tiles with the
+    tight and the ragged epilogue, split-K, the small-problem kernel) against the plain result"""
+    ops = _ops()
+    A = rnd(M, K, seed=90).to(DEV)
+    W = rnd(N, K, seed=91, scale=K ** -0.5).to(DEV)
+    b = rnd(N, seed=92).float().to(DEV)
+    plain = ops.gemm(A, W, b)
+    hm = ops.gemm(A, W, b, head_dim=hd)
+    assert tuple(hm.shape) == (N // hd, M, hd)
+    assert torch.equal(hm.permute(1, 0, 2).reshape(M, N), plain)
+
+
+def test_ref_attention_head_major_k():
+    """K (and the reference K) head-major == token-major, bit for bit"""
+    ops = _ops()
+    heads, d, Nf, T = 8, 40, 4, 256
+    Cc = heads * d
+    q, k = rnd(Nf * T, Cc, seed=93).to(DEV), rnd(Nf * T, Cc, seed=94).to(DEV)
+    vt = rnd(Cc, Nf * T, seed=95).to(DEV)
+    kref, vtref = rnd(2 * T, Cc, seed=96).to(DEV), rnd(Cc, 2 * T, seed=97).to(DEV)
+    ridx = torch.tensor([-1, 1, 0, 1], dtype=torch.int32, device=DEV)
+    want = ops.ref_attention(q, Cc, k, Cc, vt, Nf * T, Nf, T, heads, d, kref=kref, ldkr=Cc, vtref=vtref, ldvtr=2 * T,
+                             ref_index=ridx)
+    k_hm = k.reshape(Nf * T, heads, d).permute(1, 0, 2).contiguous()
+    kr_hm = kref.reshape(2 * T, heads, d).permute(1, 0, 2).contiguous()
+    got = ops.ref_attention(q, Cc, k_hm, d, vt, Nf * T, Nf, T, heads, d, kref=kr_hm, ldkr=d, vtref=vtref, ldvtr=2 * T,
+                            ref_index=ridx, k_head_stride=Nf * T * d, kref_head_stride=2 * T * d)
+    assert torch.equal(got, want)
+
+
 @pytest.mark.parametrize("B,Fr,T,heads,d", [(2, 16, 10, 8, 40), (1, 4, 7, 8, 8), (1, 24, 3, 8, 160), (2, 5, 6, 2, 16),
                                             (1, 32, 2, 8, 80)])
 def test_temporal_attention(B, Fr, T, heads, d):
