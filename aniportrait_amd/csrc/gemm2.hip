@@ -821,6 +821,7 @@ int anip_gemm2_try_splitk(const anip_gemm_params& p, hipStream_t stream) {
   anip_gemm_params q = p;
   q.out = p.workspace; q.ldo = p.N; q.out_f32 = 1;
   q.alpha = 1.0f; q.bias = nullptr; q.rowbias = nullptr; q.residual = nullptr;
+  q.head_dim = 0;            // partial tiles are plain [split][M][N]; the reduce kernel applies the output mapping
   q.batch = S; q.strideA = 0; q.strideW = 0; q.strideO = (int64_t)p.M * p.N;
   int rc;
   if (bn == 128) rc = dispatch_gemm2<128, 128, 4, 2, 32, 3>(q, stream, S);
