@@ -108,7 +108,7 @@ def _pipeline_worker(rank, world, port, q, case):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path[:0] = [here, os.path.dirname(here)]
-    torch.set_num_threads(2)
+    torch.set_num_threads(max(2, (os.cpu_count() or 4) // 2))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import emu_hipops
