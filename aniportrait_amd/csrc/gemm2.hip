@@ -858,7 +858,9 @@ int anip_gemm2_try(const anip_gemm_params& p, hipStream_t stream) {
   const bool k64 = p.conv ? (p.Cin % 64 == 0) : (p.A2 == nullptr || p.K1 % 64 == 0);
   // (round 2 microbench, 32 frames: K = 640 layers of the 32x32 level 10-12 % faster on the wide tiles — ff-in GEGLU
   // 307 -> 272 us, temporal qkv 122 -> 107, out-proj 59.9 -> 54.0; K = 320 layers no better, some worse)
-  if (k64 && force != 1 && (p.K >= 640 || force == 2)) {
+  // (with the 64-B aligned tile deal the wide tiles also win on the K = 320 layers whose output is at least two of
+  // their tiles wide — temporal qkv N = 960: 181 -> 155 us — but not on the N = 320 residual layers: 62 vs 66 us)
+  if (k64 && force != 1 && (p.K >= 640 || (p.K >= 256 && p.N >= 640) || force == 2)) {
     const int64_t pad320 = (int64_t)((p.N + 319) / 320) * 320, pad256 = (int64_t)((p.N + 255) / 256) * 256;
     int wbn = 0;
     if (p.act == 1) wbn = (pad256 * 100 <= (int64_t)p.N * 115) ? 256 : 0;   // GEGLU pairs tiles: even count per wave
