@@ -151,3 +151,41 @@ def test_wrapped_dilated_window_accumulates_like_the_reference(monkeypatch):
                                      len(w), L, HWC)
     assert torch.equal(acc, ref_acc) and torch.equal(cnt, ref_cnt)
     assert _last_occurrence_only([0, 2, 4, 0, 2]) == [-1, -1, 4, 0, 2]
+
+
+def test_aux_graph_cache_is_bounded_and_follows_the_packed_weights():
+    """the once-per-clip graph cache (ReferenceNet / PoseGuider): at most `max_cached_graphs` entries per kind, and an
+    entry dies when its module re-packs its weights (the graph has their addresses baked in)"""
+    from aniportrait_amd.pipeline_pose2vid_long import Pose2VideoPipeline
+
+    class Mod:
+        def __init__(self):
+            self.p = object()
+
+        def packed(self):
+            return self.p
+
+    pipe = Pose2VideoPipeline.__new__(Pose2VideoPipeline)
+    pipe.max_cached_graphs = 2
+    m, other = Mod(), Mod()
+    made = []
+
+    def make(tag):
+        def f():
+            made.append(tag)
+            return tag
+        return f
+
+    assert pipe._aux_graph("refnet", m, "a", make("A")) == "A"
+    assert pipe._aux_graph("refnet", m, "a", make("A2")) == "A"          # hit
+    assert pipe._aux_graph("pose", other, "a", make("P")) == "P"         # another kind: its own population
+    assert pipe._aux_graph("refnet", m, "b", make("B")) == "B"
+    assert pipe._aux_graph("refnet", m, "c", make("C")) == "C"           # evicts the oldest refnet entry ("a")
+    assert made == ["A", "P", "B", "C"]
+    assert pipe._aux_graph("refnet", m, "a", make("A3")) == "A3"
+    assert pipe._aux_graph("pose", other, "a", make("P2")) == "P"        # untouched by the refnet evictions
+    m.p = object()                                                       # weights re-packed: every refnet entry is stale
+    assert pipe._aux_graph("refnet", m, "a", make("A4")) == "A4"
+    assert sum(1 for k in pipe.__dict__["_aux_graphs"] if k[0] == "refnet") == 1
+    pipe.drop_cached_graphs()
+    assert pipe.__dict__["_aux_graphs"] == {}
