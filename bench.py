@@ -40,8 +40,9 @@ TF_VAE_FRAME = {512: 2.515, 256: 0.622}
 TF_PER_FRAME_C2 = 59.54                  # (25 * 36.43 + 1.59 + 16 * 2.515) / 16
 MFMA_PEAK_TFLOPS = 2500.0                # dense fp16, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0                    # HBM3E spec peak, MI355X_MICROARCH.md (about 6.3 TB/s is achievable)
-# HBM bytes per launch of each kernel family, from the rocprofv3 PMC passes of THIS command (tools/pmc_round.sh ->
-# tools/pmc_summarize.py; FETCH_SIZE doubled per the guide's gfx950 correction, WRITE_SIZE calibrated on a copy kernel)
+# HBM bytes per launch of each kernel family, from rocprofv3 PMC passes over the eager denoising step at this workload's
+# shapes (tools/gpu_measure.sh: tools/pmc_unet_step.py -> tools/pmc_summarize.py; FETCH_SIZE doubled per the guide's
+# gfx950 correction, both counters calibrated on an fp16 add of known size in the kernel-set pass)
 TRAFFIC_FILE = os.path.join(REPO, "profiles", "pmc_traffic_latest.json")
 
 
@@ -380,8 +381,11 @@ def main():
             fams = sorted((fam(k) for k in table), key=lambda r: -r["share_of_gpu_kernel_time"])
             dom = max((r for r in fams if r["bound"] == "mfma"), key=lambda r: r["share_of_gpu_kernel_time"])
             out["roofline"] = dict(dom, whole_clip_frac=(fps / n_gpus * TF_PER_FRAME_C2 / MFMA_PEAK_TFLOPS) if is_c2 else None,
-                                   traffic_source=("profiles/pmc_traffic_latest.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE "
-                                                   "passes of this command)") if dom["traffic"] is not None else None)
+                                   traffic_source=("profiles/pmc_traffic_latest.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) and "
+                                                   "WRITE_SIZE passes over tools/pmc_unet_step.py, the eager denoising "
+                                                   "UNet3D forward at this workload's shapes (92 % of a clip; counter "
+                                                   "collection cannot follow the graph replays of this command)")
+                                   if dom["traffic"] is not None else None)
             out["rooflines"] = fams
             out["stages"] = stage_rates(pipe, H, W, L, a.ddim_steps)
             if prof.by_shape:
