@@ -39,6 +39,8 @@ def check_script_imports(script, last_line):
     for name in ("get_fps", "read_frames", "save_videos_grid", "LMKExtractor", "FaceMeshVisualizer"):
         mod = sys.modules[ns[name].__module__]
         assert os.path.abspath(mod.__file__).startswith(os.path.join(REFERENCE, "src") + os.sep), (name, mod.__file__)
+    for name in ("init_frame_interpolation_model", "batch_images_interpolation_tool"):   # the `-acc` plumbing is shimmed too
+        assert ns[name].__module__ == "aniportrait_amd.frame_interpolation", (name, ns[name].__module__)
     assert issubclass(ns["Pose2VideoPipeline"], diffusers.DiffusionPipeline)
     # the reader control the pipelines attach comes from the same shim; context scheduler too
     from src.models.mutual_self_attention import ReferenceAttentionControl

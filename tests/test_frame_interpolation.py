@@ -1,0 +1,79 @@
+"""`-acc` frame-interpolation plumbing against the reference's OWN function
+(src/utils/frame_interpolation.py:22-68), run here with a stand-in for the FILM TorchScript blob (absent) and with
+`Tensor.cuda()` patched to a no-op: same frames, same order, bit for bit; the device-resident version batches the
+frame pairs and uploads the clip once."""
+import importlib
+import os
+import sys
+import types
+
+import pytest
+import torch
+
+REFERENCE = os.environ.get("ANIP_REFERENCE_ROOT", "/root/reference")
+needs_reference = pytest.mark.skipif(not os.path.isfile(os.path.join(REFERENCE, "src", "utils", "frame_interpolation.py")),
+                                     reason="the reference checkout only exists in the build container")
+
+
+class FakeFilm(torch.nn.Module):
+    """deterministic, batch-independent, non-linear stand-in: (x0, x1, dt) -> frame"""
+
+    def forward(self, x0, x1, dt):
+        t = dt.reshape(-1, 1, 1, 1).to(x0.dtype)
+        return (x0 * (1 - t) + x1 * t + 0.05 * torch.sin(7 * (x0 - x1)) * t * (1 - t)) * 1.02
+
+
+def _clip(bs=1, F=5, H=8, W=6, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand((bs, 3, F, H, W), generator=g)
+
+
+def _reference_tool(monkeypatch):
+    """the reference module imported from its own file, with cv2 stubbed (imported but unused there) and
+    Tensor.cuda() a no-op"""
+    monkeypatch.setitem(sys.modules, "cv2", types.ModuleType("cv2"))
+    spec = importlib.util.spec_from_file_location("ref_frame_interpolation",
+                                                  os.path.join(REFERENCE, "src", "utils", "frame_interpolation.py"))
+    mod = importlib.util.module_from_spec(spec)
+    sys.dont_write_bytecode = True
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(torch.Tensor, "cuda", lambda self, *a, **k: self)
+    monkeypatch.setattr(mod, "tqdm", lambda it: it)
+    return mod.batch_images_interpolation_tool
+
+
+@needs_reference
+@pytest.mark.parametrize("inter_frames", [1, 2, 3, 5])
+def test_matches_the_reference_function(monkeypatch, inter_frames):
+    from aniportrait_amd.frame_interpolation import batch_images_interpolation_tool
+    ref_tool = _reference_tool(monkeypatch)
+    model = FakeFilm().half()
+    x = _clip(F=5, seed=inter_frames)
+    want = ref_tool(x, model, inter_frames=inter_frames)
+    got = batch_images_interpolation_tool(x, model, inter_frames=inter_frames, device="cpu")
+    assert got.shape == want.shape == (1, 3, 4 * (inter_frames + 1) + 1, 8, 6) and got.dtype == torch.float32
+    assert torch.equal(got, want)
+    # the given frames come through untouched, in fp32
+    assert torch.equal(got[:, :, ::inter_frames + 1], x)
+
+
+def test_schedule_batching_and_edge_cases():
+    from aniportrait_amd.frame_interpolation import batch_images_interpolation_tool, insertion_schedule
+    assert [(l, r, p) for l, r, p, _, _ in insertion_schedule(1)] == [(0, 1, 1)]
+    plan3 = insertion_schedule(3)                      # middle first, then the two quarters
+    assert [(l, r, p) for l, r, p, _, _ in plan3] == [(0, 1, 1), (0, 1, 1), (2, 3, 3)]
+    assert abs(float(plan3[0][3] / plan3[0][4]) - 0.5) < 1e-6
+    model = FakeFilm().half()
+    x = _clip(bs=2, F=4, seed=9)
+    both = batch_images_interpolation_tool(x, model, inter_frames=2, device="cpu")
+    for b in range(2):                                  # samples are independent of the batching
+        one = batch_images_interpolation_tool(x[b:b + 1], model, inter_frames=2, device="cpu")
+        assert torch.equal(both[b:b + 1], one)
+    single = _clip(F=1)
+    assert torch.equal(batch_images_interpolation_tool(single, model, inter_frames=2, device="cpu"), single)
+
+
+def test_missing_blob_is_reported(tmp_path):
+    from src.utils.frame_interpolation import init_frame_interpolation_model     # the drop-in import path
+    with pytest.raises(FileNotFoundError):
+        init_frame_interpolation_model(str(tmp_path / "film_net_fp16.pt"))
