@@ -61,7 +61,8 @@ __device__ __forceinline__ void row_swap(float& x, float& y) {
 //   256 x {256,320} x 64, 8 waves 2x4 (wave tile 128 x {64,80}), 2-stage, 1 block/CU — the global->LDS traffic per
 //     flop drops by 1/4..1/3 and every DMA row is a full 128-B line (BK = 32 rows are half lines), which is what
 //     bounds the smaller tiles (measured: DMA alone = 0.93 ms of the 1.18 ms 8192^3 GEMM).
-template <int BM2, int BN, int NW, int WNW, int BKT, int NST, bool CONV, bool TRANS>
+//   SCHED = 1 (wide tiles only): the quarter-phased main loop (round 3), see "quarter-phased schedule" below.
+template <int BM2, int BN, int NW, int WNW, int BKT, int NST, bool CONV, bool TRANS, int SCHED = 0>
 __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void gemm2_kernel(const anip_gemm_params p,
                                                                                            const int dbg, const int splitk) {
   constexpr int NT2 = NW * 64;
@@ -123,28 +124,55 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
 
   // ---- per-lane DMA source bookkeeping ------------------------------------------------------------
   const int lr = lane / CPR, ls = lane % CPR;  // row within the DMA instruction's row group, 16-B slot within the row
-  uint32_t a_off[NA_I];                        // plain: byte offset of (row, chunk g) at k = 0; conv: pixel base
+  // Everything an A DMA instruction needs per lane is precomputed here, so that issuing one inside the main loop is a
+  // scalar add + a select (round 2 recomputed row * lda with 64-bit multiplies and re-read lda / lda2 from the kernel
+  // arguments for every instruction: s_load + s_waitcnt + v_mul_lo in the middle of the load segment):
+  //   plain   a_v0[i] / a_v1[i] = byte offset of (row, chunk g) at k = 0 in source 1 / source 2 (OOB if row >= M);
+  //           the K position travels in the instruction's scalar offset
+  //   conv    a_v0[i] = byte offset of channel chunk g of the window's CENTRE pixel (oy*stride, ox*stride), a_v1[i] =
+  //           bit (3 dy + dx) set iff tap (dy, dx) of this row lies inside the image; the tap / channel position is a
+  //           per-K-tile scalar delta.  Fused nearest-2x upsample (3 convs per UNet call): a_v0 = image base pixel index,
+  //           a_v1 = packed window origin (y0 + 1) << 16 | (x0 + 1) in the upsampled grid (round 2's computation).
+  uint32_t a_v0[NA_I], a_v1[NA_I];
   int a_g[NA_I];
-  int a_y0[NA_I], a_x0[NA_I];
-  bool a_ok[NA_I];
+  // RPI-row block of the A tile that this wave's i-th DMA instruction fills.  SCHED 0: blocks wave*NA_I + i.
+  // SCHED 1 (BM2 = 256, 8 waves 2 x 4, NA_I = 4): instructions 0, 1 fill "A-lo" blocks — the first 64 rows of each
+  // 128-row wave-row band — and 2, 3 the "A-hi" blocks, so that the two halves can be staged (and waited for) separately.
+  auto a_blk = [&](int i) -> int {
+    if (SCHED == 0) return wave * NA_I + i;
+    const int r = 2 * wave + (i & 1);            // 0..15 within the half
+    return (r >> 3) * 16 + (i >> 1) * 8 + (r & 7);
+  };
 #pragma unroll
   for (int i = 0; i < NA_I; ++i) {
-    const int row = (wave * NA_I + i) * RPI + lr;
+    const int row = a_blk(i) * RPI + lr;
     const int g = ls ^ swz_of<BKT>(row);
     const int m = m0 + row;
+    const bool okm = m < p.M;
     a_g[i] = g;
-    a_ok[i] = m < p.M;
     if (CONV) {
       const int hw = p.Hout * p.Wout;
-      const int mm = a_ok[i] ? m : 0;
+      const int mm = okm ? m : 0;
       const int img = mm / hw, rem = mm - img * hw;
       const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-      a_off[i] = (uint32_t)img * (uint32_t)(p.Hin * p.Win);
-      a_y0[i] = oy * p.stride - p.pad;
-      a_x0[i] = ox * p.stride - p.pad;
+      const int y0 = oy * p.stride - p.pad, x0 = ox * p.stride - p.pad;
+      if (p.upsample) {
+        a_v0[i] = okm ? (uint32_t)img * (uint32_t)(p.Hin * p.Win) : 0xFFFFFFFFu;
+        a_v1[i] = ((uint32_t)(y0 + 1) << 16) | (uint32_t)(x0 + 1);
+      } else {
+        uint32_t mask = 0;
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9) {
+          const int y = y0 + t9 / 3, x = x0 + t9 % 3;
+          if (okm && y >= 0 && y < p.Hin && x >= 0 && x < p.Win) mask |= 1u << t9;
+        }
+        a_v0[i] = (((uint32_t)img * (uint32_t)(p.Hin * p.Win) + (uint32_t)(oy * p.stride * p.Win + ox * p.stride)) * (uint32_t)p.Cin +
+                   (uint32_t)(g * 8)) * 2u;
+        a_v1[i] = mask;
+      }
     } else {
-      a_off[i] = (uint32_t)m;
-      a_y0[i] = a_x0[i] = 0;
+      a_v0[i] = okm ? (uint32_t)(((int64_t)m * p.lda + g * 8) * 2) : OOB;
+      a_v1[i] = (okm && p.A2 != nullptr) ? (uint32_t)(((int64_t)m * p.lda2 + g * 8) * 2) : OOB;
     }
   }
   uint32_t b_off[NB_I];
@@ -158,50 +186,56 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
   }
   const int my_b = (NB_TOT - wave + NW - 1) / NW;  // B DMA instructions this wave issues (wave-uniform)
 
-  auto issue = [&](int kt, int stage) {
-#ifdef ANIP_GEMM2_EXPERIMENTS
-    if (dbg & 2) return;   // experiment: no global->LDS traffic
-#endif
+  // one A / one B DMA instruction of K-tile kt into ring stage `stage`
+  auto issue_a1 = [&](int kt, int stage, int i) {
     char* sa = smem + stage * STAGE;
-    char* sb = sa + A_BYTES;
     const int k0 = kt * BKT;
     const bool ktail = k0 + BKT > p.K;         // wave-uniform
     if (CONV) {
       const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;   // tap uniform over the K-tile (Cin % BKT == 0)
       const int dy = tap / 3, dx = tap - dy * 3;
-      const int He = p.upsample ? 2 * p.Hin : p.Hin, We = p.upsample ? 2 * p.Win : p.Win;
-#pragma unroll
-      for (int i = 0; i < NA_I; ++i) {
-        int y = a_y0[i] + dy, x = a_x0[i] + dx;
-        const bool ok = a_ok[i] && y >= 0 && y < He && x >= 0 && x < We;
-        if (p.upsample) { y >>= 1; x >>= 1; }
-        const uint32_t vo = ok ? ((a_off[i] + (uint32_t)(y * p.Win + x)) * (uint32_t)p.Cin + (uint32_t)(c0 + a_g[i] * 8)) * 2u : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(sa + (wave * NA_I + i) * 1024), 16, vo, 0, 0, 0);
+      uint32_t vo;
+      if (p.upsample) {
+        int y = (int)(a_v1[i] >> 16) - 1 + dy, x = (int)(a_v1[i] & 0xFFFFu) - 1 + dx;
+        const bool ok = a_v0[i] != 0xFFFFFFFFu && y >= 0 && y < 2 * p.Hin && x >= 0 && x < 2 * p.Win;
+        y >>= 1; x >>= 1;
+        vo = ok ? ((a_v0[i] + (uint32_t)(y * p.Win + x)) * (uint32_t)p.Cin + (uint32_t)(c0 + a_g[i] * 8)) * 2u : OOB;
+      } else {
+        const int delta = (((dy - p.pad) * p.Win + (dx - p.pad)) * p.Cin + c0) * 2;     // scalar
+        vo = ((a_v1[i] >> tap) & 1u) ? a_v0[i] + (uint32_t)delta : OOB;
       }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(sa + a_blk(i) * 1024), 16, vo, 0, 0, 0);
     } else {
       const bool second = (p.A2 != nullptr) && (k0 >= p.K1);   // wave-uniform (K1 % BKT == 0)
       const int kk = second ? k0 - p.K1 : k0;
-      const int64_t ld = second ? p.lda2 : p.lda;
-      const int klim = second ? p.K - p.K1 : (p.A2 ? p.K1 : p.K);
-#pragma unroll
-      for (int i = 0; i < NA_I; ++i) {
-        uint32_t vo = a_ok[i] ? (uint32_t)(((int64_t)a_off[i] * ld + kk + a_g[i] * 8) * 2) : OOB;
-        if (ktail && kk + a_g[i] * 8 >= klim) vo = OOB;
-        if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA2, LDS_PTR(sa + (wave * NA_I + i) * 1024), 16, vo, 0, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(sa + (wave * NA_I + i) * 1024), 16, vo, 0, 0, 0);
+      uint32_t vo = second ? a_v1[i] : a_v0[i];
+      if (ktail) {
+        const int klim = second ? p.K - p.K1 : (p.A2 ? p.K1 : p.K);
+        if (kk + a_g[i] * 8 >= klim) vo = OOB;
       }
+      if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA2, LDS_PTR(sa + a_blk(i) * 1024), 16, vo, (uint32_t)kk * 2u, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(sa + a_blk(i) * 1024), 16, vo, (uint32_t)kk * 2u, 0, 0);
     }
+  };
+  auto issue_b1 = [&](int kt, int stage, int i) {
+    char* sb = smem + stage * STAGE + A_BYTES;
+    const int k0 = kt * BKT;
+    uint32_t vo = b_off[i];
+    if (k0 + BKT > p.K) {
+      const int row = (wave + NW * i) * RPI + lr;
+      if (k0 + (ls ^ swz_of<BKT>(row)) * 8 >= p.K) vo = OOB;
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(sb + (wave + NW * i) * 1024), 16, vo, (uint32_t)k0 * 2u, 0, 0);
+  };
+  auto issue = [&](int kt, int stage) {
+#ifdef ANIP_GEMM2_EXPERIMENTS
+    if (dbg & 2) return;   // experiment: no global->LDS traffic
+#endif
 #pragma unroll
-    for (int i = 0; i < NB_I; ++i) {
-      if (i < my_b) {
-        uint32_t vo = b_off[i];
-        if (ktail) {
-          const int row = (wave + NW * i) * RPI + lr;
-          if (k0 + (ls ^ swz_of<BKT>(row)) * 8 >= p.K) vo = OOB;
-        }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(sb + (wave + NW * i) * 1024), 16, vo, (uint32_t)k0 * 2u, 0, 0);
-      }
-    }
+    for (int i = 0; i < NA_I; ++i) issue_a1(kt, stage, i);
+#pragma unroll
+    for (int i = 0; i < NB_I; ++i)
+      if (i < my_b) issue_b1(kt, stage, i);
   };
 
   // ---- fragment read offsets ------------------------------------------------------------------------
@@ -257,7 +291,117 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
     nk = max(0, min(nk - kt_begin, per));
   }
   constexpr bool PHASED = (NST == 2 && KH == 2 && NW == 8);
-  if (PHASED) {
+  if constexpr (PHASED && SCHED == 1) {
+    // Quarter-phased schedule (round 3).  Round 2's role-alternating loop below issues the WHOLE next K-tile (8-9 LDS-DMA
+    // instructions per wave, 36 KiB per wave group through the CU's one 64 B/clk address path) inside ONE of its four
+    // load segments per K-tile and drains it (vmcnt(0)) once per K-tile: that segment is ~3x longer than the 32-MFMA
+    // compute segment of the partner wave it is supposed to hide behind, and the matrix pipe waits at the barrier.
+    // Here a K-tile is FOUR sub-steps of 4 x NB MFMAs (a wave's 128 x WTN tile as [A-lo | A-hi] x [k-half 0 | 1]), the
+    // next tile's DMA is dealt over the four load segments — B first half, B second half, A-lo, A-hi: 2-3 instructions
+    // each — and the queue is never drained: counted vmcnt at two points per tile,
+    //   sub-step order   j=0: A-lo x B(kh0)   j=1: A-lo x B(kh1)   j=2: A-hi x B(kh1)   j=3: A-hi x B(kh0)
+    //   LOAD(j) reads    bf0, af               bf1, af               af                   af        (bf0 / bf1 stay live)
+    //   LOAD(j) stages   B[0:half) of t+1      B[half:) of t+1       A-lo of t+1          A-hi of t+1
+    //   wait before bar  lgkm                  vmcnt(NB_I): A-hi(t)  lgkm                 vmcnt(2): all of t+1 but A-hi
+    // A-hi of tile t+1, staged last, is first read at j=2 of tile t+1 and waited for at the end of LOAD(j=1) there: four
+    // segments to land.  Waves 4-7 run one barrier behind waves 0-3 as before (a wave's compute segment coincides with
+    // its SIMD partner's load segment).  Hazards, with barrier #b closing interval I(b); group 0 runs LOAD(s) in I(2s)
+    // and COMPUTE(s) in I(2s+1), group 1 LOAD(s) in I(2s+1), COMPUTE(s) in I(2s+2), s = 4t + j:
+    //   RAW  every wave waits for its own DMA share before a barrier that every reader passes before it reads: the
+    //        j=3 wait of tile t is before #8t+6 (group 0) / #8t+7 (group 1), the first reads of tile t+1 come after
+    //        #8t+7 / #8t+8; the j=1 wait before #8t+2 / #8t+3, the A-hi reads after #8t+3 / #8t+4.
+    //   WAR  a region of the other stage is re-staged in tile t at the sub-step AFTER the one that last read it in tile
+    //        t-1 (B: j=0/1, read last at j=1; A-lo: j=2, read last at j=1; A-hi: j=3, read last at j=3 of t-1, i.e. four
+    //        segments earlier), and every LOAD ends with lgkmcnt(0) before its barrier.
+    static_assert(FM == 8 && NA_I == 4 && NB_TOT % NW == 0, "quarter-phased schedule: 256-row tile, 2 x 4 waves");
+    constexpr int HALF_B = NB_TOT / 2;
+    // B instruction i of this wave fills row block wave + NW * i: first half of B?  (a constant after unrolling except
+    // for the one i whose blocks straddle the middle: BN = 320, i = 2)
+    auto b_first = [&](int i) -> bool {
+      return (NW * i + NW - 1 < HALF_B) ? true : ((NW * i >= HALF_B) ? false : (wave + NW * i < HALF_B));
+    };
+    const int grp = wave >> 2;
+    if (nk > 0) issue(kt_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    f16x8 bf0[NB], bf1[NB], af[4];
+    const int a_lo = a_row_off, a_hi = a_row_off + 64 * RB;
+#define ANIP_G2_BAR()                      \
+    __builtin_amdgcn_sched_barrier(0);     \
+    __builtin_amdgcn_s_barrier();          \
+    __builtin_amdgcn_sched_barrier(0)
+#define ANIP_G2_MMA(I0, BF)                                                                               \
+    __builtin_amdgcn_s_setprio(1);                                                                        \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < NB; ++j)          \
+        acc[(I0) + i][j] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], BF[j], acc[(I0) + i][j], 0, 0, 0) \
+                                 : __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[j], af[i], acc[(I0) + i][j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0)
+    for (int t = 0; t < nk; ++t) {
+      const char* sa = smem + (t & 1) * STAGE;
+      const char* sb = sa + A_BYTES;
+      const int nst = (t + 1) & 1;
+      const bool more = t + 1 < nk;                 // block-uniform
+      const int ktn = kt_begin + t + 1;
+      // ---- j = 0: A-lo x B(k-half 0); stage the first half of B of tile t+1
+#pragma unroll
+      for (int j = 0; j < NB; ++j) bf0[j] = *(const f16x8*)(sb + (tile_c(j) + fr) * RB + koff[0]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *(const f16x8*)(sa + a_lo + i * 16 * RB + koff[0]);
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < NB_I; ++i)
+          if (b_first(i)) issue_b1(ktn, nst, i);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      ANIP_G2_BAR();
+      ANIP_G2_MMA(0, bf0);
+      ANIP_G2_BAR();
+      // ---- j = 1: A-lo x B(k-half 1); stage the second half of B; A-hi of THIS tile must have landed
+#pragma unroll
+      for (int j = 0; j < NB; ++j) bf1[j] = *(const f16x8*)(sb + (tile_c(j) + fr) * RB + koff[1]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *(const f16x8*)(sa + a_lo + i * 16 * RB + koff[1]);
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < NB_I; ++i)
+          if (!b_first(i)) issue_b1(ktn, nst, i);
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NB_I) : "memory");   // every wave stages NB_I B blocks per tile
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+      ANIP_G2_BAR();
+      ANIP_G2_MMA(0, bf1);
+      ANIP_G2_BAR();
+      // ---- j = 2: A-hi x B(k-half 1); stage A-lo of tile t+1
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *(const f16x8*)(sa + a_hi + i * 16 * RB + koff[1]);
+      if (more) {
+        issue_a1(ktn, nst, 0);
+        issue_a1(ktn, nst, 1);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      ANIP_G2_BAR();
+      ANIP_G2_MMA(4, bf1);
+      ANIP_G2_BAR();
+      // ---- j = 3: A-hi x B(k-half 0); stage A-hi of tile t+1; everything of tile t+1 but that must have landed
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *(const f16x8*)(sa + a_hi + i * 16 * RB + koff[0]);
+      if (more) {
+        issue_a1(ktn, nst, 2);
+        issue_a1(ktn, nst, 3);
+        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      }
+      ANIP_G2_BAR();
+      ANIP_G2_MMA(4, bf0);
+      ANIP_G2_BAR();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+#undef ANIP_G2_BAR
+#undef ANIP_G2_MMA
+  } else if (PHASED) {
     // Role-alternating schedule for the one-block-per-CU wide tiles.  A K-tile is two 32-deep steps; every step is a
     // LOAD segment (all ds_reads of the step's fragments, plus the DMA issue of the next K-tile on the first step)
     // and a COMPUTE segment (FM x NB MFMAs on registers only), each closed by an s_barrier.  Waves 4-7 run one
@@ -685,13 +829,13 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
   }
 }
 
-template <int BM2, int BN, int NW, int WNW, int BKT, int NST, bool CONV, bool TRANS>
+template <int BM2, int BN, int NW, int WNW, int BKT, int NST, bool CONV, bool TRANS, int SCHED = 0>
 int launch_gemm2(const anip_gemm_params& p, hipStream_t stream, int splitk = 1) {
   constexpr int NT2 = NW * 64;
   constexpr int LDS = NST * (BM2 + BN) * BKT * 2;
   static bool attr_done = false;
   if (!attr_done) {
-    auto kfn = gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS>;
+    auto kfn = gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS, SCHED>;
     if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
       anip_set_error("anip_gemm: cannot raise the dynamic LDS limit to %d bytes", LDS);
       return -2;
@@ -700,13 +844,27 @@ int launch_gemm2(const anip_gemm_params& p, hipStream_t stream, int splitk = 1) 
   }
   static const int dbg = getenv("ANIP_GEMM2_DBG") ? atoi(getenv("ANIP_GEMM2_DBG")) : 0;  // kernel experiments only
   const int nbm = (p.M + BM2 - 1) / BM2, nbn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS>), dim3((unsigned)(nbm * nbn), (unsigned)p.batch, 1),
+  hipLaunchKernelGGL((gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS, SCHED>), dim3((unsigned)(nbm * nbn), (unsigned)p.batch, 1),
                      dim3(NT2), LDS, stream, p, dbg, splitk);
   return 1;
 }
 
+// main-loop schedule of the wide (256-row, BK = 64, one block per CU) tiles: 1 = quarter-phased (round 3, default),
+// 0 = round 2's role-alternating loop (ANIP_GEMM2_SCHED=0; kept for A/B measurements)
+static int gemm2_sched() {
+  static const int v = getenv("ANIP_GEMM2_SCHED") ? atoi(getenv("ANIP_GEMM2_SCHED")) : 1;
+  return v;
+}
+
 template <int BM2, int BN, int NW, int WNW, int BKT, int NST>
 int dispatch_gemm2(const anip_gemm_params& p, hipStream_t stream, int splitk = 1) {
+  if constexpr (NST == 2 && BKT == 64 && NW == 8) {
+    if (gemm2_sched() == 1) {
+      if (p.conv) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, true, false, 1>(p, stream, splitk);
+      if (p.trans_out) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, true, 1>(p, stream, splitk);
+      return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, false, 1>(p, stream, splitk);
+    }
+  }
   if (p.conv) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, true, false>(p, stream, splitk);
   if (p.trans_out) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, true>(p, stream, splitk);
   return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, false>(p, stream, splitk);

@@ -21,6 +21,7 @@ Legal shortcuts relative to the reference's op sequence (identical results, SURV
   * skip-concat / nearest-2x upsample / time-embedding add / residual adds are fused into the
     neighbouring GroupNorm / conv / GEMM kernels.
 """
+import itertools
 import math
 import os
 
@@ -40,10 +41,15 @@ _UP_HAS_ATTN = (False, True, True, True)
 class PackedNet:
     """Kernel-ready weights of one network on one device.  `sd`: reference-format state-dict."""
 
+    _serials = itertools.count(1)
+
     def __init__(self, sd, device):
         self.device = torch.device(device)
         self.sd = sd
         self.t = {}
+        # process-unique, never reused: captured hipGraphs are keyed on it (`id()` of a freed PackedNet can be handed to
+        # its replacement by the allocator, which would let a stale graph replay against freed weight addresses)
+        self.serial = next(PackedNet._serials)
 
     # -- accessors (packed lazily, cached) ---------------------------------------------------------
     def _raw(self, name):
@@ -403,14 +409,15 @@ class Attn2Cache:
 
 
 def unet_forward(net, cfg, x, b, f, t, ehs, attn2_cache, refs, with_motion, ref_index=None, pose_nhwc=None,
-                 final=True, stop_after_last_bank=False, temb_in=None, attn2_refresh=True):
+                 final=True, stop_after_last_bank=False, temb_in=None, attn2_refresh=True, tap=None):
     """UNet3DConditionModel.forward (src/models/unet_3d.py:399-580) / the ReferenceNet
     UNet2DConditionModel.forward (src/models/unet_2d_condition.py:872-1308, f = 1, no motion modules).
 
     x (b*f, h, w, 4) fp16 channels-last.  ehs (b, 1, D).  refs: {path: RefState}.  ref_index: (int32 tensor (b*f,), n) —
     reference sample per frame, -1 for the CFG-unconditional frames that attend to self only
     (src/models/mutual_self_attention.py:77-85,166-186), and the number n of frames that do have one.  pose_nhwc: list of 5 channels-last tensors or None.  Returns (b*f, h, w, out_channels) fp16 (or the last hidden state if
-    `final` is False; None if `stop_after_last_bank`).
+    `final` is False; None if `stop_after_last_bank`).  tap(name, x): optional observer of every block output
+    (channels-last; tools/bisect_parity.py compares them with the oracle's, block by block).
     """
     if ehs.shape[1] != 1:
         raise NotImplementedError("encoder_hidden_states with sequence length != 1: the pose2vid path feeds "
@@ -436,18 +443,23 @@ def unet_forward(net, cfg, x, b, f, t, ehs, attn2_cache, refs, with_motion, ref_
     a2 = attn2_cache.get(net, cfg, ehs, attn2_refresh)
     last_path = attention_paths(cfg)[-1]
 
+    def see(p, x):
+        if tap is not None and x is not None:
+            tap(p, x)
+        return x
+
     def res(p, x, skip=None):
         o, c = toffs[p + ".time_emb_proj"]
         hw = x.shape[1] * x.shape[2]
-        return resnet(net, p, x, skip, temb_all[:, o:o + c], f * hw, eps, groups)
+        return see(p, resnet(net, p, x, skip, temb_all[:, o:o + c], f * hw, eps, groups))
 
     def attn(p, x):
-        return spatial_transformer(net, p, x, heads, a2[p], f, refs.get(p), ref_index,
-                                   stop_after_bank=stop_after_last_bank and p == last_path)
+        return see(p, spatial_transformer(net, p, x, heads, a2[p], f, refs.get(p), ref_index,
+                                          stop_after_bank=stop_after_last_bank and p == last_path))
 
     def mm(p, x):
         if with_motion and net.has(p + ".temporal_transformer.proj_in.weight"):
-            return motion_module(net, p, x, b, f, cfg["motion_module_kwargs"]["num_attention_heads"])
+            return see(p, motion_module(net, p, x, b, f, cfg["motion_module_kwargs"]["num_attention_heads"]))
         return x
 
     def add_pose(x, i):
@@ -457,6 +469,7 @@ def unet_forward(net, cfg, x, b, f, t, ehs, attn2_cache, refs, with_motion, ref_
 
     x = ops.conv_direct(x, net.conv_direct("conv_in.weight"), net.f32("conv_in.bias"), boc[0], 3, 1, 1,
                         residual=None if pose_nhwc is None else pose_nhwc[0])
+    see("conv_in", x)
     skips = [x]
     for i in range(nblk):
         for j in range(lpb):
@@ -467,7 +480,7 @@ def unet_forward(net, cfg, x, b, f, t, ehs, attn2_cache, refs, with_motion, ref_
             skips.append(x)
         if i != nblk - 1:
             pn = f"down_blocks.{i}.downsamplers.0.conv"
-            x = ops.conv3x3(x, net.conv3(pn + ".weight"), net.f32(pn + ".bias"), stride=2, pad=1)
+            x = see(pn[:-5], ops.conv3x3(x, net.conv3(pn + ".weight"), net.f32(pn + ".bias"), stride=2, pad=1))
             skips.append(x)
         x = add_pose(x, i + 1)
     x = res("mid_block.resnets.0", x)
@@ -484,13 +497,13 @@ def unet_forward(net, cfg, x, b, f, t, ehs, attn2_cache, refs, with_motion, ref_
             x = mm(f"up_blocks.{i}.motion_modules.{j}", x)
         if i != nblk - 1:
             pn = f"up_blocks.{i}.upsamplers.0.conv"
-            x = ops.conv3x3(x, net.conv3(pn + ".weight"), net.f32(pn + ".bias"), upsample=True)
+            x = see(pn[:-5], ops.conv3x3(x, net.conv3(pn + ".weight"), net.f32(pn + ".bias"), upsample=True))
     if not final or not net.has("conv_out.weight"):
         return x
     C = x.shape[-1]
     h = ops.groupnorm(x.reshape(N, H * W, C), net.f32("conv_norm_out.weight"), net.f32("conv_norm_out.bias"), groups,
                       eps, True)
-    return ops.conv3x3(h.reshape(N, H, W, C), net.conv3("conv_out.weight"), net.f32("conv_out.bias"))
+    return see("conv_out", ops.conv3x3(h.reshape(N, H, W, C), net.conv3("conv_out.weight"), net.f32("conv_out.bias")))
 
 
 # ----------------------------------------------------------------------------------------------------

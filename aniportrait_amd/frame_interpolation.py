@@ -59,10 +59,15 @@ def _dt(like, numer, denom, batch):
 
 
 @torch.no_grad()
-def batch_images_interpolation_tool(input_tensor, model, inter_frames=1, device=None, output_device="cpu"):
+def batch_images_interpolation_tool(input_tensor, model, inter_frames=1, device=None, output_device="cpu",
+                                    pair_chunk=16):
     """input_tensor (bs, C, F, H, W) in [0, 1] -> (bs, C, (F-1)(inter_frames+1)+1, H, W) fp32 on `output_device`
     (src/utils/frame_interpolation.py:22-68).  `device`: where the model lives (default: the model's own parameters /
-    cuda)."""
+    cuda).  `pair_chunk`: frame pairs per model call (FILM's full-resolution feature pyramids cost 0.1-1 GB per pair at
+    512-768 px, so a long clip is walked in row slices; the schedule and the output layout do not depend on it; None =
+    all pairs in one call).  Bit-equality with the reference's pairwise loop is established for a batch-independent
+    stand-in model (tests/test_frame_interpolation.py); with the real FILM checkpoint (absent here) batched fp16
+    convolutions may pick other MIOpen algorithms than batch 1 — untested."""
     bs, C, F, H, W = input_tensor.shape
     n = int(inter_frames)
     if device is None:
@@ -80,7 +85,11 @@ def batch_images_interpolation_tool(input_tensor, model, inter_frames=1, device=
     results = [first, second]
     for left, right, pos, numer, denom in insertion_schedule(n):
         x0, x1 = results[left], results[right]
-        pred = model(x0, x1, _dt(x0, numer, denom, x0.shape[0]))
+        rows = x0.shape[0]
+        step = rows if not pair_chunk else max(1, int(pair_chunk))
+        preds = [model(x0[s:s + step], x1[s:s + step], _dt(x0, numer, denom, min(step, rows - s)))
+                 for s in range(0, rows, step)]
+        pred = preds[0] if len(preds) == 1 else torch.cat(preds, dim=0)
         results.insert(pos, pred.clamp(0, 1).to(torch.float16))
     # (bs*P, n+1, C, H, W): each pair's first frame followed by its n inserted ones; the originals keep their fp32 values
     out = torch.empty((bs, C, P * (n + 1) + 1, H, W), dtype=torch.float32, device=output_device)

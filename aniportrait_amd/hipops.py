@@ -41,13 +41,39 @@ K_CONV_SMALL, K_LINEAR_SMALL, K_ELEMENTWISE, K_BATCHNORM = 8, 9, 10, 11
 _FLOP_KERNELS = (K_GEMM, K_CONV3X3, K_REF_ATTN)
 _WORK = None  # kernel id -> algorithmic work (flops for 0,1,5; bytes otherwise) while profiling
 _CALLS = None  # [(kernel id, shape descriptor, work)] in launch order while profiling
+_ABYTES = None  # parallel to _CALLS: algorithmic HBM bytes (operands read once + outputs written once) per call
 
 
-def _work(kid, amount, desc=""):
-    """one call per library-side event bracket, in launch order (profile() pairs them up by position)"""
+def _work(kid, amount, desc="", abytes=None):
+    """one call per library-side event bracket, in launch order (profile() pairs them up by position).  `abytes`:
+    algorithmic bytes of a FLOP-counted kernel (byte-counted kernels: `amount` itself)"""
     if _WORK is not None:
         _WORK[kid] = _WORK.get(kid, 0) + amount
         _CALLS.append((kid, desc, amount))
+        if _ABYTES is not None:
+            _ABYTES.append(int(abytes) if abytes is not None else (0 if kid in _FLOP_KERNELS else int(amount)))
+
+
+class trace_calls:
+    """`with trace_calls() as t: ...; t.calls` -> [{family, shape, work, unit, algorithmic_bytes}] of every wrapper call
+    in launch order, WITHOUT the library-side event brackets (for rocprofv3 --pmc passes: tools/pmc_unet_step.py writes
+    this list next to the counter CSVs and tools/pmc_summarize.py pairs it with the dispatch rows by order, which is
+    what tells a 3x3 conv from a Linear and one shape from another — the kernel symbol alone cannot)."""
+
+    def __enter__(self):
+        global _WORK, _CALLS, _ABYTES
+        _WORK, _CALLS, _ABYTES = {}, [], []
+        self.calls = None
+        return self
+
+    def __exit__(self, *exc):
+        global _WORK, _CALLS, _ABYTES
+        lib = L.load()
+        self.calls = [dict(family=lib.anip_profile_kernel_name(k).decode(), shape=desc, work=w,
+                           unit="FLOP" if k in _FLOP_KERNELS else "B", algorithmic_bytes=ab)
+                      for (k, desc, w), ab in zip(_CALLS, _ABYTES)]
+        _WORK = _CALLS = _ABYTES = None
+        return False
 
 
 class profile:
@@ -313,7 +339,12 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
                     f"{' A2' if A2 is not None else ''}{' rb' if rowbias is not None else ''}"
                     f"{' res' if residual is not None else ''}{' T' if trans_out else ''}{' f32' if out_f32 else ''}"
                     f"{' hm' if head_dim else ''}")
-        _work(K_CONV3X3 if conv is not None else K_GEMM, 2 * M * N * K * max(1, int(p.batch)), desc)
+        nb = max(1, int(p.batch))
+        a_bytes = (conv["Nimg"] * conv["Hin"] * conv["Win"] * conv["Cin"] if conv is not None else
+                   M * K * (nb if (not batched or A.dim() == 3) else 1)) * 2
+        w_bytes = N * K * 2 * (nb if (batched and W.dim() == 3) else 1)
+        o_bytes = M * n_out * nb * (4 if out_f32 else 2) + (M * n_out * 2 if residual is not None else 0)
+        _work(K_CONV3X3 if conv is not None else K_GEMM, 2 * M * N * K * nb, desc, a_bytes + w_bytes + o_bytes)
     if M <= 16384:   # few output tiles: the library may want fp32 scratch for split-K
         wsb = lib.anip_gemm_workspace_bytes(C.byref(p))
         if wsb > 0:
@@ -333,7 +364,8 @@ def ffn_geglu(x, w1p, b1p, w2, b2, residual=None):
     M, Cc = x.shape
     assert tuple(w1p.shape) == (8 * Cc, Cc) and tuple(w2.shape) == (Cc, 4 * Cc)
     out = torch.empty_like(x)
-    _work(K_GEMM, 2 * M * Cc * (8 * Cc) + 2 * M * Cc * (4 * Cc), f"ffn_geglu M{M} C{Cc}")
+    _work(K_GEMM, 2 * M * Cc * (8 * Cc) + 2 * M * Cc * (4 * Cc), f"ffn_geglu M{M} C{Cc}",
+          M * Cc * 2 * (3 if residual is not None else 2) + 12 * Cc * Cc * 2)
     L.check(lib.anip_ffn_geglu(_p(x), _p(w1p), _p(_req(b1p, F32, "b1p")), _p(w2), _p(b2), _p(residual), _p(out), M, Cc,
                                _stream()), "anip_ffn_geglu")
     return out
@@ -420,7 +452,8 @@ def ref_attention(q, ldq, k, ldk, vt, ldvt, n_frames, T, heads, d, kref=None, ld
     (heads, tokens, d)): ldk = d and k_head_stride = tokens * d."""
     lib = L.load()
     _work(K_REF_ATTN, 4 * T * T * heads * d * (n_frames + (n_ref_frames if ref_index is not None else 0)),
-          f"Nf{n_frames} T{T} h{heads} d{d} ref{n_ref_frames if ref_index is not None else 0}")
+          f"Nf{n_frames} T{T} h{heads} d{d} ref{n_ref_frames if ref_index is not None else 0}",
+          2 * heads * d * (4 * n_frames * T + (2 * kref.numel() // (heads * d) if kref is not None else 0)))
     out = torch.empty((n_frames * T, heads * d), dtype=F16, device=q.device)
     if scale is None:
         scale = d ** -0.5

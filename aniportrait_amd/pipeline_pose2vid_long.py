@@ -371,23 +371,29 @@ class Pose2VideoPipeline(_Base):
         re-packs its weights (a captured graph has the packed tensors' addresses baked in) and bounded to
         `max_cached_graphs` entries (`drop_cached_graphs()` empties it)."""
         unet = self.denoising_unet
-        tag = (id(unet), id(unet.packed()))
+        tag = (id(unet), unet.packed().serial)
         if self.__dict__.get("_runner_tag") != tag:
             self.__dict__["_runner_tag"] = tag
             self.__dict__["_runners"] = OrderedDict()
         return self.__dict__["_runners"]
 
     def drop_cached_graphs(self):
-        """release every captured graph (denoising step, ReferenceNet, PoseGuider) and its static buffers"""
+        """release every captured graph (denoising step, ReferenceNet, PoseGuider), its static buffers, and the per-shape
+        reference-projection / attn2 pools the graphs had baked in (safe once no graph references them: a process serving
+        many resolutions would otherwise grow without bound)"""
         self.__dict__["_runners"] = OrderedDict()
         self.__dict__.pop("_runner_tag", None)
         self.__dict__["_aux_graphs"] = {}
+        for name in ("denoising_unet", "reference_unet"):
+            drop = getattr(getattr(self, name, None), "drop_reference_pools", None)
+            if drop is not None:
+                drop()
 
     def _aux_graph(self, kind, module, key, make):
         """{(kind, key): _GraphedFn} for the once-per-clip networks; an entry dies with the module's packed weights
         (their addresses are baked into the graph) and the per-kind population is bounded like the step graphs"""
         cache = self.__dict__.setdefault("_aux_graphs", {})
-        tag = (id(module), id(module.packed()))
+        tag = (id(module), module.packed().serial)
         live = {k: v for k, v in cache.items() if k[0] != kind or v[0] == tag}
         mine = [k for k in live if k[0] == kind]
         if (kind, key) not in live:
@@ -634,7 +640,12 @@ class Pose2VideoPipeline(_Base):
         that used them has been consumed (or dropped), so the frames of clip i can still be draining / waiting for their
         consumer while clips i+1, i+2 ... are produced."""
         import weakref
-        st = self.__dict__.setdefault("_d2h", {"stream": torch.cuda.Stream(device=video.device), "bufs": {}})
+        # one side stream + pinned-slot table PER DEVICE (a pipeline moved to / shared across GPUs must not enqueue the
+        # copy on a stream of another device)
+        per_dev = self.__dict__.setdefault("_d2h", {})
+        st = per_dev.get(str(video.device))
+        if st is None:
+            st = per_dev[str(video.device)] = {"stream": torch.cuda.Stream(device=video.device), "bufs": {}}
         slots = st["bufs"].setdefault((tuple(video.shape), video.dtype), [])
         slot = None
         for sl in slots:

@@ -85,6 +85,11 @@ class _UNetBase(HipModel):
 
     def _invalidate(self):
         super()._invalidate()
+        self.drop_reference_pools()
+
+    def drop_reference_pools(self):
+        """free the per-shape K_ref / V_ref^T and collapsed-attn2 buffers (only legal while no captured graph reads
+        them: the pipeline calls this from `drop_cached_graphs`, `_invalidate` when the weights change)"""
         if "_attn2_cache" in self.__dict__:
             self._attn2_cache.drop()
             for rb in self._ref_blocks.values():
@@ -124,7 +129,7 @@ class _UNetBase(HipModel):
         engine.prepare_reference(self.packed(), self.config, self._engine_refs(), encoder_hidden_states, self._attn2_cache)
 
     def forward_nhwc(self, x, b, f, timestep, encoder_hidden_states, pose_nhwc=None, final=True,
-                     stop_after_last_bank=False, temb_in=None, attn2_refresh=True):
+                     stop_after_last_bank=False, temb_in=None, attn2_refresh=True, tap=None):
         """channels-last entry used by the pipeline: x (b*f, h, w, C) fp16 on the GPU.  temb_in: device fp32
         (b, C0) timestep sinusoid replacing `timestep` (see engine.unet_forward).  attn2_refresh=False: reuse the
         collapsed-attn2 vectors the previous forward computed for this batch size (engine.Attn2Cache)."""
@@ -133,7 +138,7 @@ class _UNetBase(HipModel):
         ridx = self._ref_index(b, f, refs, net.device)
         out = engine.unet_forward(net, self.config, x, b, f, timestep, encoder_hidden_states, self._attn2_cache,
                                   refs, self.three_d, ridx, pose_nhwc, final, stop_after_last_bank, temb_in,
-                                  attn2_refresh)
+                                  attn2_refresh, tap)
         for p, rb in self._ref_blocks.items():  # write mode: append to module.bank like the hacked forward
             if rb.state.mode == "write" and rb.state.written is not None:
                 rb.node.bank.append(rb.state.written)

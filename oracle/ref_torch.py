@@ -201,11 +201,17 @@ _DOWN_HAS_ATTN = (True, True, True, False)
 _UP_HAS_ATTN = (False, True, True, True)
 
 
-def _unet_body(sd, cfg, x, emb, ehs_rows, f, mode, banks, n_uncond, pose_fea, with_motion):
+def _unet_body(sd, cfg, x, emb, ehs_rows, f, mode, banks, n_uncond, pose_fea, with_motion, tap=None):
     """Shared SD-1.5 topology walk (unet_3d.py:484-570 / unet_2d_condition.py:1136-1296).
 
     x (N, 4, h, w) with N = b*f; ehs_rows (N, 1, D); banks: dict path -> tensor (read) or list (write).
+    tap(name, x) -> x: optional observer / modifier of every block output (tools/bisect_parity.py: per-block error
+    tables, and the "fp16-storage" variant of this oracle that rounds every block output to fp16).
     """
+    if tap is None:
+        def tap(name, x):
+            return x
+
     heads = cfg["attention_head_dim"]
     eps = cfg["norm_eps"]
     nblk = len(cfg["block_out_channels"])
@@ -237,37 +243,38 @@ def _unet_body(sd, cfg, x, emb, ehs_rows, f, mode, banks, n_uncond, pose_fea, wi
 
     temb = emb.repeat_interleave(f, dim=0) if emb.shape[0] != x.shape[0] else emb
     x = _conv(sd, "conv_in", x)
-    x = add_pose(x, 0)
+    x = tap("conv_in", add_pose(x, 0))
     skips = [x]
     for i in range(nblk):
         for j in range(lpb):
-            x = resnet_block(sd, f"down_blocks.{i}.resnets.{j}", x, temb, eps)
+            x = tap(f"down_blocks.{i}.resnets.{j}", resnet_block(sd, f"down_blocks.{i}.resnets.{j}", x, temb, eps))
             if _DOWN_HAS_ATTN[i]:
-                x = attn(f"down_blocks.{i}.attentions.{j}", x)
-            x = mm(f"down_blocks.{i}.motion_modules.{j}", x)
+                x = tap(f"down_blocks.{i}.attentions.{j}", attn(f"down_blocks.{i}.attentions.{j}", x))
+            x = tap(f"down_blocks.{i}.motion_modules.{j}", mm(f"down_blocks.{i}.motion_modules.{j}", x))
             skips.append(x)
         if i != nblk - 1:
             x = _conv(sd, f"down_blocks.{i}.downsamplers.0.conv", x, stride=2, padding=1)
+            x = tap(f"down_blocks.{i}.downsamplers.0", x)
             skips.append(x)
         x = add_pose(x, i + 1)
-    x = resnet_block(sd, "mid_block.resnets.0", x, temb, eps)
-    x = attn("mid_block.attentions.0", x)
-    x = mm("mid_block.motion_modules.0", x)
-    x = resnet_block(sd, "mid_block.resnets.1", x, temb, eps)
+    x = tap("mid_block.resnets.0", resnet_block(sd, "mid_block.resnets.0", x, temb, eps))
+    x = tap("mid_block.attentions.0", attn("mid_block.attentions.0", x))
+    x = tap("mid_block.motion_modules.0", mm("mid_block.motion_modules.0", x))
+    x = tap("mid_block.resnets.1", resnet_block(sd, "mid_block.resnets.1", x, temb, eps))
     for i in range(nblk):
         for j in range(lpb + 1):
             x = torch.cat([x, skips.pop()], dim=1)
-            x = resnet_block(sd, f"up_blocks.{i}.resnets.{j}", x, temb, eps)
+            x = tap(f"up_blocks.{i}.resnets.{j}", resnet_block(sd, f"up_blocks.{i}.resnets.{j}", x, temb, eps))
             if _UP_HAS_ATTN[i]:
-                x = attn(f"up_blocks.{i}.attentions.{j}", x)
-            x = mm(f"up_blocks.{i}.motion_modules.{j}", x)
+                x = tap(f"up_blocks.{i}.attentions.{j}", attn(f"up_blocks.{i}.attentions.{j}", x))
+            x = tap(f"up_blocks.{i}.motion_modules.{j}", mm(f"up_blocks.{i}.motion_modules.{j}", x))
         if i != nblk - 1:
             x = F.interpolate(x, scale_factor=2.0, mode="nearest")
-            x = _conv(sd, f"up_blocks.{i}.upsamplers.0.conv", x)
+            x = tap(f"up_blocks.{i}.upsamplers.0", _conv(sd, f"up_blocks.{i}.upsamplers.0.conv", x))
     return x
 
 
-def unet3d_forward(sd, cfg, sample, t, ehs, pose_fea=None, banks=None, do_cfg=True):
+def unet3d_forward(sd, cfg, sample, t, ehs, pose_fea=None, banks=None, do_cfg=True, tap=None):
     """UNet3DConditionModel.forward (unet_3d.py:399-580). sample (b,4,f,h,w); ehs (b,1,D).
     banks: dict path -> (b,T,C) (already fp16-rounded) or None for the un-hacked block."""
     b, c, f, h, w = sample.shape
@@ -276,9 +283,11 @@ def unet3d_forward(sd, cfg, sample, t, ehs, pose_fea=None, banks=None, do_cfg=Tr
     ehs_rows = ehs.repeat_interleave(f, dim=0)
     mode = "read" if banks is not None else "plain"
     n_uncond = (b * f) // 2 if (do_cfg and banks is not None) else 0
-    x = _unet_body(sd, cfg, x, emb, ehs_rows, f, mode, banks, n_uncond, pose_fea, True)
+    x = _unet_body(sd, cfg, x, emb, ehs_rows, f, mode, banks, n_uncond, pose_fea, True, tap)
     x = F.silu(_gn(sd, "conv_norm_out", x, cfg["norm_eps"]))
     x = _conv(sd, "conv_out", x)
+    if tap is not None:
+        x = tap("conv_out", x)
     return x.reshape(b, f, -1, h, w).permute(0, 2, 1, 3, 4)
 
 

@@ -46,3 +46,23 @@ def pipe_inputs(name):
     return dict(H=H, W=W, L=L, steps=steps, cfg=cfg, long=long, kw=kw,
                 poses=synth_pose_frames(L, H, W), ref_pose=synth_pose_frames(1, H, W, 999)[0],
                 ref_image=synth_ref_image(H, W), latents=synth_latents(L, H // 8, W // 8, 42))
+
+
+# Real-width (SD-1.5 / sd-vae-ft-mse widths) pipeline cases whose outputs the REFERENCE's own pipeline produced in the
+# build container (oracle/make_golden_real_pipeline.py -> tests/golden/real_pipeline_<name>.pt); the GPU tests only
+# compare against the committed fixture (no CPU oracle run on the GPU box).
+REAL_PIPE_CASES = {
+    # name: (H, W, L, steps, cfg, input seed, frames whose decoded pixels are stored)
+    "c2_4step": (512, 512, 16, 4, 3.5, 2, tuple(range(16))),      # BASELINE configs[1] geometry, 4 of 25 DDIM steps
+    "c5_1step": (768, 768, 16, 1, 3.5, 3, (0, 5, 10, 15)),        # BASELINE configs[4] geometry (96x96 latents)
+    "l40_windows": (128, 128, 40, 3, 3.5, 4, (0, 11, 12, 23, 36, 39)),  # 4 windows / step incl. the wrap-around one
+}
+
+
+def real_pipe_inputs(name):
+    from aniportrait_amd.synthetic import synth_pose_frames, synth_ref_image
+
+    H, W, L, steps, cfg, seed, frames = REAL_PIPE_CASES[name]
+    return dict(H=H, W=W, L=L, steps=steps, cfg=cfg, seed=seed, frames=frames, gen_seed=42 + seed,
+                ref_image=synth_ref_image(H, W, 1 + seed), poses=synth_pose_frames(L, H, W, 1234 + 100 * seed),
+                ref_pose=synth_pose_frames(1, H, W, 999)[0])

@@ -700,3 +700,95 @@ def test_ffn_geglu_fused(M):
     # same rounding points as the two-GEMM path (bit-identical when that path does not split K: tools/exp_ffn.py)
     two = ops.gemm(ops.gemm(x, w1p.to(DEV), b1p.to(DEV), act=1), W2.to(DEV), b2.to(DEV), residual=res.to(DEV))
     close(out, two, f"ffn_geglu fused vs two GEMMs M={M}", rtol=2e-3, arms=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------
+# wide tiles (256 x {256,320} x 64, one block per CU): the quarter-phased main loop of round 3 (ANIP_GEMM2_SCHED=1,
+# default; =0 selects round 2's loop) with every A loader (plain, two-source, 3x3 window, stride 2, fused upsample),
+# every epilogue, ragged M / N / K tails, short and odd K-tile counts, and a repeated-run race screen (the schedule
+# keeps LDS-DMA in flight across barriers with counted vmcnt: a misplaced wait shows as rare wrong tiles)
+# ------------------------------------------------------------------------------------------------
+def _ref_mm_gpu(A, W):
+    """fp32 reference on the device for the large wide-tile problems (a CPU fp64 matmul of 10^11 MACs takes minutes):
+    fp32 inputs, highest precision"""
+    return (A.float() @ W.float().t()).cpu()
+
+
+@pytest.mark.parametrize("M,N,K", [(65536, 640, 640), (50000, 600, 1000), (49152, 768, 64 * 5), (65536, 320, 64 * 11),
+                                   (16384, 4096, 512), (49408, 960, 320)])
+def test_gemm2_wide_plain(M, N, K):
+    ops = _ops()
+    A = rnd(M, K, seed=201).to(DEV)
+    W = rnd(N, K, seed=202, scale=K ** -0.5).to(DEV)
+    bias = rnd(N, seed=203).float().to(DEV)
+    ref = _ref_mm_gpu(A, W) + bias.cpu()
+    out = ops.gemm(A, W, bias)
+    close(out, ref, f"gemm2 wide {M}x{N}x{K}")
+    for _ in range(5):                                       # race screen: identical results on every run
+        assert torch.equal(ops.gemm(A, W, bias), out)
+
+
+def test_gemm2_wide_epilogues_two_source_trans():
+    ops = _ops()
+    M, K1, K2, N = 65536, 320, 640, 320
+    A1 = rnd(M, K1, seed=204).to(DEV)
+    A2 = rnd(M, K2, seed=205).to(DEV)
+    W = rnd(N, K1 + K2, seed=206, scale=(K1 + K2) ** -0.5).to(DEV)
+    bias = rnd(N, seed=207).float().to(DEV)
+    rowbias = rnd(16, N, seed=208).float().to(DEV)
+    res = rnd(M, N, seed=209).to(DEV)
+    base = _ref_mm_gpu(torch.cat([A1, A2], 1), W)
+    out = ops.gemm(A1, W, bias, A2=A2, rowbias=rowbias, rows_per_group=4096, residual=res)
+    ref = base + bias.cpu() + rowbias.cpu().repeat_interleave(4096, dim=0) + res.float().cpu()
+    close(out, ref, "gemm2 wide two-source + bias + rowbias + residual")
+    # row groups that change inside a 256-row tile
+    rb2 = rnd(M // 100 + 1, N, seed=210).float().to(DEV)
+    out = ops.gemm(A1, W, bias, A2=A2, rowbias=rb2, rows_per_group=100)
+    close(out, base + bias.cpu() + rb2.cpu().repeat_interleave(100, dim=0)[:M], "gemm2 wide ragged row groups")
+    Wt = rnd(640, 640, seed=211, scale=640 ** -0.5).to(DEV)
+    bt = rnd(640, seed=212).float().to(DEV)
+    outT = ops.gemm(A2, Wt, bt, trans_out=True)
+    close(outT, (_ref_mm_gpu(A2, Wt) + bt.cpu()).t(), "gemm2 wide transposed out")
+    outH = ops.gemm(A2, Wt, bt, head_dim=80)
+    close(outH, (_ref_mm_gpu(A2, Wt) + bt.cpu()).reshape(M, 8, 80).permute(1, 0, 2), "gemm2 wide head-major out")
+    out32 = ops.gemm(A2, Wt, None, alpha=0.25, out_f32=True)
+    close(out32, 0.25 * _ref_mm_gpu(A2, Wt), "gemm2 wide alpha fp32-out", rtol=1e-3, arms=1e-3)
+    # GEGLU on the 256-wide tiles
+    Cc = 640
+    Wg = rnd(8 * Cc, Cc, seed=213, scale=Cc ** -0.5)
+    bg = rnd(8 * Cc, seed=214).float()
+    Wp, bp = ops.pack_geglu(Wg, bg)
+    Ag = A2[:32768].contiguous()
+    outg = ops.gemm(Ag, Wp.to(DEV), bp.to(DEV), act=1)
+    h, g = (_ref_mm_gpu(Ag, Wg.to(DEV)) + bg).chunk(2, dim=-1)
+    close(outg, h * F.gelu(g), "gemm2 wide GEGLU")
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,stride,pad,pad_hi,up", [
+    (16, 64, 64, 128, 320, 1, 1, 1, False),      # 256 x 320 tiles, K = 1152 (18 K-tiles)
+    (16, 32, 32, 128, 320, 1, 1, 1, True),       # fused nearest-2x upsample
+    (16, 128, 128, 64, 640, 2, 1, 1, False),     # stride 2
+    (13, 67, 61, 192, 250, 1, 1, 1, False),      # ragged M and N (256-wide tiles), K = 1728 (27 K-tiles: odd count)
+    (16, 129, 129, 64, 640, 2, 0, 1, False),     # asymmetric padding (VAE encoder downsample)
+])
+def test_gemm2_wide_conv3x3(N, H, W, Cin, Cout, stride, pad, pad_hi, up):
+    ops = _ops()
+    x = rnd(N, H, W, Cin, seed=220).to(DEV)
+    w = rnd(Cout, Cin, 3, 3, seed=221, scale=(9 * Cin) ** -0.5)
+    b = rnd(Cout, seed=222).float()
+    wp = ops.pack_conv3x3(w).to(DEV)
+    out = ops.conv3x3(x, wp, b.to(DEV), stride=stride, pad=pad, upsample=up, pad_hi=pad_hi)
+    xr = x.float().permute(0, 3, 1, 2)
+    if up:
+        xr = F.interpolate(xr, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(F.pad(xr, (pad, pad_hi, pad, pad_hi)), w.float().to(DEV), b.to(DEV), stride=stride).permute(0, 2, 3, 1)
+    close(out, ref, f"gemm2 wide conv3x3 {N}x{H}x{W} {Cin}->{Cout} s{stride} p{pad}/{pad_hi} up={up}")
+    for _ in range(3):
+        assert torch.equal(ops.conv3x3(x, wp, b.to(DEV), stride=stride, pad=pad, upsample=up, pad_hi=pad_hi), out)
+    if not up and stride == 1:
+        temb = rnd(2, Cout, seed=223).float().to(DEV)
+        res = rnd(*out.shape, seed=224).to(DEV)
+        rpg = (out.shape[0] * out.shape[1] * out.shape[2] + 1) // 2
+        out2 = ops.conv3x3(x, wp, b.to(DEV), rowbias=temb, rows_per_group=rpg, residual=res)
+        idx = (torch.arange(out.numel() // Cout) // rpg).reshape(out.shape[:3])
+        close(out2, ref.cpu() + temb.cpu()[idx] + res.float().cpu(), "gemm2 wide conv3x3 + temb rowbias + residual")

@@ -158,9 +158,11 @@ def test_aux_graph_cache_is_bounded_and_follows_the_packed_weights():
     entry dies when its module re-packs its weights (the graph has their addresses baked in)"""
     from aniportrait_amd.pipeline_pose2vid_long import Pose2VideoPipeline
 
+    from aniportrait_amd.engine import PackedNet
+
     class Mod:
         def __init__(self):
-            self.p = object()
+            self.p = PackedNet({}, "cpu")
 
         def packed(self):
             return self.p
@@ -184,7 +186,11 @@ def test_aux_graph_cache_is_bounded_and_follows_the_packed_weights():
     assert made == ["A", "P", "B", "C"]
     assert pipe._aux_graph("refnet", m, "a", make("A3")) == "A3"
     assert pipe._aux_graph("pose", other, "a", make("P2")) == "P"        # untouched by the refnet evictions
-    m.p = object()                                                       # weights re-packed: every refnet entry is stale
+    # weights re-packed in the hostile order (HipModel._invalidate drops the old PackedNet BEFORE packed() builds the new
+    # one, so CPython may hand the new object the old one's address): the tag is the never-reused serial, not id()
+    old_serial, m.p = m.p.serial, None
+    m.p = PackedNet({}, "cpu")
+    assert m.p.serial != old_serial
     assert pipe._aux_graph("refnet", m, "a", make("A4")) == "A4"
     assert sum(1 for k in pipe.__dict__["_aux_graphs"] if k[0] == "refnet") == 1
     pipe.drop_cached_graphs()
