@@ -79,8 +79,8 @@ class AutoencoderKL(HipModel):
         self.use_slicing = False
 
     # channels-last entry points used by the pipeline
-    def decode_nhwc(self, z):
-        return engine.vae_decode(self.packed(), self.config, z)
+    def decode_nhwc(self, z, tap=None):
+        return engine.vae_decode(self.packed(), self.config, z, tap)
 
     def encode_mean_nhwc(self, x):
         return engine.vae_encode_mean(self.packed(), self.config, x)

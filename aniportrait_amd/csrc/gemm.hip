@@ -105,8 +105,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_small_kernel(const anip_gemm
     const bool kval = kk < p.K;
     if (CONV) {
       const int k0 = kt * BK;
-      const int tap = k0 / p.Cin;    // uniform over the tile (Cin % 64 == 0)
-      const int c = kk - tap * p.Cin;
+      // conv = 1: tap-major K; conv = 2: channel-block-major K [Cin/64][9 taps][64] (see hipops.pack_conv3x3)
+      const int tap = p.conv == 2 ? (k0 % 576) >> 6 : k0 / p.Cin;    // uniform over the tile (Cin % 64 == 0, BK = 64)
+      const int c = p.conv == 2 ? (k0 / 576) * 64 + g * 8 : kk - tap * p.Cin;
       const int dy = tap / 3, dx = tap - dy * 3;
       const int He = p.upsample ? 2 * p.Hin : p.Hin, We = p.upsample ? 2 * p.Win : p.Win;
 #pragma unroll
@@ -327,6 +328,7 @@ extern "C" int anip_gemm(const anip_gemm_params* pp, void* stream) {
   if (p.conv) {
     ANIP_REQUIRE(p.Cin % 64 == 0, "anip_gemm(conv): Cin=%d must be a multiple of 64", p.Cin);
     ANIP_REQUIRE(p.K == 9 * p.Cin, "anip_gemm(conv): K must equal 9*Cin");
+    ANIP_REQUIRE(p.conv == 1 || p.conv == 2, "anip_gemm(conv): conv must be 1 (tap-major K) or 2 (channel-block-major K)");
     ANIP_REQUIRE((int64_t)p.Nimg * p.Hout * p.Wout == (int64_t)p.M, "anip_gemm(conv): M != Nimg*Hout*Wout");
     ANIP_REQUIRE(p.A2 == nullptr, "anip_gemm(conv): two-source A not supported");
     ANIP_REQUIRE(!p.upsample || (p.stride == 1 && p.pad == 1 && p.Hout == 2 * p.Hin && p.Wout == 2 * p.Win),

@@ -192,7 +192,17 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
     const int k0 = kt * BKT;
     const bool ktail = k0 + BKT > p.K;         // wave-uniform
     if (CONV) {
-      const int tap = k0 / p.Cin, c0 = k0 - tap * p.Cin;   // tap uniform over the K-tile (Cin % BKT == 0)
+      // (tap, first channel) of the K-tile; uniform over it.  conv = 1: tap-major K (Cin % BKT == 0); conv = 2:
+      // channel-block-major K, [Cin/64][9 taps][64] (Cin % 64 == 0): the nine taps of a channel block are consecutive
+      int tap, c0;
+      if (p.conv == 2) {
+        const int cb = k0 / 576, r = k0 - cb * 576;
+        tap = r >> 6;
+        c0 = cb * 64 + (r & 63);
+      } else {
+        tap = k0 / p.Cin;
+        c0 = k0 - tap * p.Cin;
+      }
       const int dy = tap / 3, dx = tap - dy * 3;
       uint32_t vo;
       if (p.upsample) {

@@ -91,9 +91,10 @@ def broadcast_tensors(tensors, src=0, group=None):
 
 def gather_frames(local_frames, local_idx, n_frames, dst=0, group=None, owner_fn=None):
     """local_frames (n_local, ...) holding global frame indices `local_idx`; returns the (n_frames, ...) tensor on
-    `dst` (None elsewhere).  Ranks may own different frame counts: every rank sends one buffer padded to the largest
-    share, and ONLY `dst` receives (dist.gather) — the frame indices of every rank follow from the sharding rule
-    (`owner_fn(rank) -> indices`, default round robin), so they are not communicated."""
+    `dst` (None elsewhere).  Ranks may own different frame counts: every rank sends EXACTLY its share point-to-point
+    (`batch_isend_irecv` into exact-size staging buffers on `dst`; round 2 padded every rank to the largest share for
+    `dist.gather`) — the frame indices of every rank follow from the sharding rule (`owner_fn(rank) -> indices`,
+    default round robin), so they are not communicated."""
     rank, ws = world(group)
     dev = local_frames.device
     if ws == 1:
@@ -102,16 +103,28 @@ def gather_frames(local_frames, local_idx, n_frames, dst=0, group=None, owner_fn
         return out
     owner_fn = owner_fn or (lambda r: shard_round_robin(n_frames, r, ws))
     assert list(local_idx) == list(owner_fn(rank)), "gather_frames: local_idx does not follow the sharding rule"
-    per = max(len(owner_fn(r)) for r in range(ws))
-    pad = torch.zeros((per,) + tuple(local_frames.shape[1:]), dtype=local_frames.dtype, device=dev)
-    pad[: local_frames.shape[0]] = local_frames
-    bufs = [torch.empty_like(pad) for _ in range(ws)] if rank == dst else None
-    dist.gather(pad, bufs, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
+    g = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    tail = tuple(local_frames.shape[1:])
     if rank != dst:
+        if len(local_idx):
+            for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, local_frames.contiguous(), g(dst), group)]):
+                w.wait()
         return None
-    out = torch.empty((n_frames,) + tuple(local_frames.shape[1:]), dtype=local_frames.dtype, device=dev)
-    for r, b in enumerate(bufs):
-        idx = owner_fn(r)
-        if idx:
-            out[torch.as_tensor(idx, dtype=torch.long, device=dev)] = b[: len(idx)]
+    out = torch.empty((n_frames,) + tail, dtype=local_frames.dtype, device=dev)
+    ops_, staged = [], []
+    for r in range(ws):
+        idx = list(owner_fn(r))
+        if not idx:
+            continue
+        if r == dst:
+            out[torch.as_tensor(idx, dtype=torch.long, device=dev)] = local_frames
+            continue
+        buf = torch.empty((len(idx),) + tail, dtype=local_frames.dtype, device=dev)
+        staged.append((idx, buf))
+        ops_.append(dist.P2POp(dist.irecv, buf, g(r), group))
+    if ops_:
+        for w in dist.batch_isend_irecv(ops_):
+            w.wait()
+    for idx, buf in staged:
+        out[torch.as_tensor(idx, dtype=torch.long, device=dev)] = buf
     return out

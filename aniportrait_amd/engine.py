@@ -510,8 +510,9 @@ def unet_forward(net, cfg, x, b, f, t, ehs, attn2_cache, refs, with_motion, ref_
 # VAE (diffusers AutoencoderKL, sd-vae-ft-mse topology)
 # ----------------------------------------------------------------------------------------------------
 
-def _vae_mid(net, p, x):
-    x = resnet(net, p + ".resnets.0", x, None, None, 0, 1e-6)
+def _vae_mid(net, p, x, see=None):
+    see = see or (lambda name, x: x)
+    x = see(p + ".resnets.0", resnet(net, p + ".resnets.0", x, None, None, 0, 1e-6))
     N, H, W, C = x.shape
     T = H * W
     a = p + ".attentions.0"
@@ -526,30 +527,36 @@ def _vae_mid(net, p, x):
     pm = ops.softmax_rows(s)
     vt = ops.gemm(net.lin(a + ".to_v.weight"), t, None, batch=N)  # (N, C, T) = W_v t^T per frame
     o = ops.gemm(pm, vt, None, batch=N)  # (N, T, C)
-    x = ops.gemm(o.reshape(N * T, C), net.lin(a + ".to_out.0.weight"), net.vae_attn_out(a),
-                 residual=x.reshape(N * T, C)).reshape(N, H, W, C)
-    return resnet(net, p + ".resnets.1", x, None, None, 0, 1e-6)
+    x = see(a, ops.gemm(o.reshape(N * T, C), net.lin(a + ".to_out.0.weight"), net.vae_attn_out(a),
+                        residual=x.reshape(N * T, C)).reshape(N, H, W, C))
+    return see(p + ".resnets.1", resnet(net, p + ".resnets.1", x, None, None, 0, 1e-6))
 
 
-def vae_decode(net, cfg, z):
+def vae_decode(net, cfg, z, tap=None):
     """AutoencoderKL.decode(z).sample, batched over frames (src/pipelines/pipeline_pose2vid_long.py:119-120
-    decodes frame by frame; frames are independent).  z (N, h, w, 4) fp16 -> (N, 8h, 8w, 3) fp16."""
+    decodes frame by frame; frames are independent).  z (N, h, w, 4) fp16 -> (N, 8h, 8w, 3) fp16.
+    tap(name, x): optional observer of every block output (tests/bisect_parity.py)."""
+    def see(name, x):
+        if tap is not None:
+            tap(name, x)
+        return x
+
     nb = len(cfg["block_out_channels"])
     x = ops.conv_direct(z, net.conv_direct("post_quant_conv.weight"), net.f32("post_quant_conv.bias"),
                         cfg["latent_channels"], 1, 1, 0)
-    x = ops.conv_direct(x, net.conv_direct("decoder.conv_in.weight"), net.f32("decoder.conv_in.bias"),
-                        cfg["block_out_channels"][-1], 3, 1, 1)
-    x = _vae_mid(net, "decoder.mid_block", x)
+    x = see("decoder.conv_in", ops.conv_direct(x, net.conv_direct("decoder.conv_in.weight"), net.f32("decoder.conv_in.bias"),
+                                               cfg["block_out_channels"][-1], 3, 1, 1))
+    x = _vae_mid(net, "decoder.mid_block", x, see)
     for i in range(nb):
         for j in range(cfg["layers_per_block"] + 1):
-            x = resnet(net, f"decoder.up_blocks.{i}.resnets.{j}", x, None, None, 0, 1e-6)
+            x = see(f"decoder.up_blocks.{i}.resnets.{j}", resnet(net, f"decoder.up_blocks.{i}.resnets.{j}", x, None, None, 0, 1e-6))
         if i != nb - 1:
             pn = f"decoder.up_blocks.{i}.upsamplers.0.conv"
-            x = ops.conv3x3(x, net.conv3(pn + ".weight"), net.f32(pn + ".bias"), upsample=True)
+            x = see(pn[:-5], ops.conv3x3(x, net.conv3(pn + ".weight"), net.f32(pn + ".bias"), upsample=True))
     N, H, W, C = x.shape
-    h = ops.groupnorm(x.reshape(N, H * W, C), net.f32("decoder.conv_norm_out.weight"),
-                      net.f32("decoder.conv_norm_out.bias"), 32, 1e-6, True)
-    return ops.conv3x3(h.reshape(N, H, W, C), net.conv3("decoder.conv_out.weight"), net.f32("decoder.conv_out.bias"))
+    h = see("decoder.conv_norm_out", ops.groupnorm(x.reshape(N, H * W, C), net.f32("decoder.conv_norm_out.weight"),
+                                                   net.f32("decoder.conv_norm_out.bias"), 32, 1e-6, True).reshape(N, H, W, C))
+    return see("decoder.conv_out", ops.conv3x3(h, net.conv3("decoder.conv_out.weight"), net.f32("decoder.conv_out.bias")))
 
 
 def vae_encode_mean(net, cfg, x):

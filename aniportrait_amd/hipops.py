@@ -6,6 +6,7 @@ tensors that own the outputs.  Activations are channels-last fp16: (N, H, W, C) 
 No fallbacks: a missing library or a non-GPU tensor raises.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -188,10 +189,35 @@ def device_info():
 # weight packing (host side, once)
 # ------------------------------------------------------------------------------------------------
 
-def pack_conv3x3(w):
-    """torch conv weight [Cout, Cin, 3, 3] -> [Cout, 9*Cin] (tap-major, channels contiguous)."""
+# K order of the implicit-GEMM 3x3 convolution (anip_gemm_params.conv):
+#   1  tap-major          W [Cout][ky][kx][Cin]: all channels of tap 0, then tap 1, ...
+#   2  channel-block-major W [Cout][Cin/64][ky][kx][64]: the nine taps of a 64-channel block are CONSECUTIVE K-tiles, so
+#      the nine shifted re-reads of an input line follow each other within ~9 K-tiles instead of Cin/64 x 9 apart — the
+#      re-reads then hit the XCD's 4 MB L2 (32 CUs x 245 KB of live input rows + the weights do not fit it in tap-major
+#      order at 64x64 x 320 channels; rocprofv3 FETCH_SIZE showed 4x the algorithmic bytes).  Needs Cin % 64 == 0.
+CONV_KORDER = int(os.environ.get("ANIP_CONV_KORDER", "2"))
+
+
+def conv_korder(cin):
+    return 2 if (CONV_KORDER == 2 and cin % 64 == 0) else 1
+
+
+def pack_conv3x3(w, order=None):
+    """torch conv weight [Cout, Cin, 3, 3] -> [Cout, 9*Cin] in the K order `order` (default: conv_korder(Cin))."""
     co, ci, kh, kw = w.shape
+    order = conv_korder(ci) if order is None else order
+    if order == 2:
+        return w.reshape(co, ci // 64, 64, kh, kw).permute(0, 1, 3, 4, 2).reshape(co, kh * kw * ci).contiguous()
     return w.permute(0, 2, 3, 1).reshape(co, kh * kw * ci).contiguous()
+
+
+def unpack_conv3x3(wp, cin, order=None):
+    """inverse of pack_conv3x3: [Cout, 9*Cin] -> [Cout, Cin, 3, 3] (tests / the CPU emulation of the wrappers)"""
+    co = wp.shape[0]
+    order = conv_korder(cin) if order is None else order
+    if order == 2:
+        return wp.reshape(co, cin // 64, 3, 3, 64).permute(0, 1, 4, 2, 3).reshape(co, cin, 3, 3)
+    return wp.reshape(co, 3, 3, cin).permute(0, 3, 1, 2)
 
 
 def pack_geglu(w, b):
@@ -284,7 +310,7 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
         M = conv["Nimg"] * conv["Hout"] * conv["Wout"]
         K = 9 * conv["Cin"]
         N = W.shape[0]
-        p.conv = 1
+        p.conv = int(conv.get("korder", 1))
         for k in ("Nimg", "Hin", "Win", "Cin", "Hout", "Wout", "stride", "pad"):
             setattr(p, k, int(conv[k]))
         p.upsample = int(bool(conv.get("upsample", False)))
@@ -372,16 +398,18 @@ def ffn_geglu(x, w1p, b1p, w2, b2, residual=None):
 
 
 def conv3x3(x, Wp, bias, stride=1, pad=1, upsample=False, pad_hi=None, rowbias=None, rows_per_group=0,
-            residual=None, out_f32=False):
+            residual=None, out_f32=False, korder=None):
     """x (N, H, W, Cin) fp16, Wp (Cout, 9*Cin) packed by pack_conv3x3 -> (N, Ho, Wo, Cout).
-    pad = low-side padding; pad_hi (default = pad) = high-side padding (VAE encoder uses 0/1)."""
+    pad = low-side padding; pad_hi (default = pad) = high-side padding (VAE encoder uses 0/1).
+    korder: the K order Wp was packed in (default: pack_conv3x3's default for this Cin)."""
     N, H, Wd, Cin = x.shape
     if pad_hi is None:
         pad_hi = pad
     He, We = (2 * H, 2 * Wd) if upsample else (H, Wd)
     Ho = (He + pad + pad_hi - 3) // stride + 1
     Wo = (We + pad + pad_hi - 3) // stride + 1
-    conv = dict(Nimg=N, Hin=H, Win=Wd, Cin=Cin, Hout=Ho, Wout=Wo, stride=stride, pad=pad, upsample=upsample)
+    conv = dict(Nimg=N, Hin=H, Win=Wd, Cin=Cin, Hout=Ho, Wout=Wo, stride=stride, pad=pad, upsample=upsample,
+                korder=conv_korder(Cin) if korder is None else korder)
     res2 = residual.reshape(-1, Wp.shape[0]) if residual is not None else None
     out = gemm(x, Wp, bias, rowbias=rowbias, rows_per_group=rows_per_group, residual=res2, conv=conv,
                out_f32=out_f32)

@@ -81,9 +81,10 @@ def clip_inputs(H, W, L, seed):
                 ref_pose=synth_pose_frames(1, H, W, 999)[0], latents=synth_latents(L, H // 8, W // 8, 42 + seed))
 
 
-def run_clip(pipe, inp, H, W, L, steps, cfg):
-    return pipe(inp["ref_image"], inp["poses"], inp["ref_pose"], W, H, L, steps, cfg, generator=None,
-                latents=inp["latents"]).videos
+def run_clip(pipe, inp, H, W, L, steps, cfg, **kw):
+    out = pipe(inp["ref_image"], inp["poses"], inp["ref_pose"], W, H, L, steps, cfg, generator=None,
+               latents=inp["latents"], **kw)
+    return None if out is None else out.videos
 
 
 def stage_rates(pipe, H, W, L, steps, reps=8):
@@ -244,7 +245,17 @@ def main():
     ap.add_argument("--extra-configs", action="store_true",
                     help="after the headline run also time BASELINE configs[3] (L=150, 13 windows) and configs[4] (768x768)")
     ap.add_argument("--table-dir", default=None, help="also write the per-kernel / per-shape table here")
+    ap.add_argument("--long-clip", action="store_true",
+                    help="BASELINE configs[3] instead of the headline: ONE 150-frame clip per step (13 context windows per DDIM "
+                         "step), sharded over the ranks with `dp_group` (windows dealt to ranks, rank 0's ReferenceNet banks "
+                         "broadcast, one all-reduce of the window sums per step, frames decoded per rank and gathered): "
+                         "STRONG scaling of one clip, not independent clips")
+    ap.add_argument("--no-async-leg", dest="async_output", action="store_false",
+                    help="skip the extra leg after the headline: the same clips with output_type='uint8' + async_output=True "
+                         "(display bytes made on the device, clip i's frames draining through pinned memory under clip i+1)")
     a = ap.parse_args()
+    if a.long_clip:
+        a.frames = 150
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -264,13 +275,18 @@ def main():
 
     H = W = a.size
     L = a.frames
-    pipe = build_pipeline(device, H, W, seed=rank)
-    inputs = [clip_inputs(H, W, L, seed=rank * 100 + i) for i in range(2)]
+    # long-clip mode: every rank works on the SAME clip with the SAME weights
+    pipe = build_pipeline(device, H, W, seed=0 if a.long_clip else rank)
+    inputs = [clip_inputs(H, W, L, seed=(0 if a.long_clip else rank * 100) + i) for i in range(2)]
+    clip_kw = {}
+    if a.long_clip and world > 1:
+        clip_kw["dp_group"] = torch.distributed.group.WORLD
 
     first = {}
     for i in range(a.warmup):
-        v = run_clip(pipe, inputs[i % 2], H, W, L, a.ddim_steps, 3.5)
-        first.setdefault(i % 2, v)
+        v = run_clip(pipe, inputs[i % 2], H, W, L, a.ddim_steps, 3.5, **clip_kw)
+        if v is not None:
+            first.setdefault(i % 2, v)
 
     def barrier():
         if world > 1:
@@ -281,7 +297,7 @@ def main():
     t0 = time.perf_counter()
     vids = []
     for i in range(a.steps):
-        vids.append((i % 2, run_clip(pipe, inputs[i % 2], H, W, L, a.ddim_steps, 3.5)))
+        vids.append((i % 2, run_clip(pipe, inputs[i % 2], H, W, L, a.ddim_steps, 3.5, **clip_kw)))
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -293,6 +309,9 @@ def main():
     # refresh picked up the right clip), and the two clips must differ
     repeats, worst = 0, float("inf")
     for k, v in vids:
+        if v is None:           # long-clip mode: only rank 0 receives the frames
+            assert a.long_clip and rank != 0
+            continue
         assert tuple(v.shape) == (1, 3, L, H, W) and bool(torch.isfinite(v).all())
         if k in first:
             repeats += 1
@@ -304,21 +323,41 @@ def main():
         assert not torch.equal(first[0], first[1]), "two different clips produced the same video"
 
     if rank == 0:
-        frames = n_gpus * a.steps * L
+        frames = (1 if a.long_clip else n_gpus) * a.steps * L
         fps = frames / elapsed
         out = {
-            "metric": "generated frames/sec, 512x512 L=16 25-step pose2vid",
+            "metric": ("generated frames/sec, 512x512 L=150 25-step pose2vid long clip" if a.long_clip else
+                       "generated frames/sec, 512x512 L=16 25-step pose2vid"),
             "value": fps, "unit": "frames/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if a.long_clip else "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"pose2vid {H}x{W}, L={L}, {a.ddim_steps} DDIM steps, CFG=3.5, fp16, one {L}-frame clip "
-                                   "per step per GPU (BASELINE.json configs[1])",
-                       "frames_per_step": L, "parallelism": f"dp{n_gpus} over independent clips"},
+            "config": ({"workload": f"pose2vid {H}x{W}, L={L} (13 context windows of 16 frames per DDIM step), {a.ddim_steps} "
+                                    "DDIM steps, CFG=3.5, fp16, ONE clip per step sharded over the GPUs (BASELINE.json configs[3])",
+                        "frames_per_step": L, "parallelism": f"dp{n_gpus} over the context windows of one clip (dp_group): "
+                                                             "bank broadcast + one all-reduce per DDIM step + frame gather"}
+                       if a.long_clip else
+                       {"workload": f"pose2vid {H}x{W}, L={L}, {a.ddim_steps} DDIM steps, CFG=3.5, fp16, one {L}-frame clip "
+                                    "per step per GPU (BASELINE.json configs[1])",
+                        "frames_per_step": L, "parallelism": f"dp{n_gpus} over independent clips"}),
             "repeat_check": {"repeated_clips": repeats, "bit_identical": bool(repeats and worst == float("inf")),
                              "min_psnr_db": None if worst == float("inf") else worst},
         }
         is_c2 = (H == 512 and L == 16 and a.ddim_steps == 25)
-        if not a.no_roofline:
+        if a.async_output and not a.long_clip:
+            # f4: display bytes made on the device, frames of clip i draining through pinned memory on a side
+            # stream while clip i+1 is generated; reported BESIDE the headline, never instead of it
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            pend = [pipe(inputs[i % 2]["ref_image"], inputs[i % 2]["poses"], inputs[i % 2]["ref_pose"], W, H, L, a.ddim_steps, 3.5,
+                         latents=inputs[i % 2]["latents"], output_type="uint8", async_output=True).videos for i in range(a.steps)]
+            outs = [p_.result() for p_ in pend]
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            assert all(o.dtype == torch.uint8 and tuple(o.shape) == (L, H, W, 3) for o in outs)
+            out["async_uint8_output"] = {"frames_per_s": a.steps * L / dt, "ms_per_clip": dt / a.steps * 1e3,
+                                         "note": "same clips, output_type='uint8' + async_output=True (quarter of the D2H "
+                                                 "bytes, copy on a side stream under the next clip); rank 0 only"}
+        if not a.no_roofline and not a.long_clip:
             from aniportrait_amd import hipops
             # two profiled clips, per-launch MINIMUM: an event bracket on an otherwise idle stream occasionally absorbs a
             # host-side hiccup (tens of ms on a 60-us kernel in round 1's table); the same record of an identical second

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ANIP_ABI_VERSION 9
+#define ANIP_ABI_VERSION 10
 
 int anip_version(void);
 const char* anip_last_error(void);
@@ -78,8 +78,11 @@ typedef struct anip_gemm_params {
   int act;                               /* 0 none; 1 GEGLU: W/bias rows packed per 32 as [16 x h | 16 x gate]
                                             (N % 128 == 0), out[M][N/2] = h * gelu_erf(gate) */
   int batch; int64_t strideA, strideW, strideO; /* batched GEMM over blockIdx.y (elements) */
-  /* implicit 3x3 convolution (conv != 0): A is an NHWC image batch, M = Nimg*Hout*Wout, K = 9*Cin,
-   * W = [Cout][3][3][Cin].  upsample=1 fuses nearest-2x (resnet.py:72-74) into the gather. */
+  /* implicit 3x3 convolution (conv != 0): A is an NHWC image batch, M = Nimg*Hout*Wout, K = 9*Cin.
+   * conv = 1: tap-major K, W = [Cout][3][3][Cin].  conv = 2 (Cin % 64 == 0): channel-block-major K,
+   * W = [Cout][Cin/64][3][3][64] — the nine taps of a 64-channel block are consecutive K-tiles, so the nine shifted
+   * re-reads of an input line stay inside the XCD's L2 (the packing the engine uses; hipops.pack_conv3x3).
+   * upsample=1 fuses nearest-2x (resnet.py:72-74) into the gather. */
   int conv; int Nimg, Hin, Win, Cin, Hout, Wout, stride, pad, upsample;
   int trans_out;                         /* 1: store the result transposed, out[n*ldo + m] (fp16; bias only):
                                             V^T = (x W_v^T)^T for anip_ref_attention */

@@ -306,30 +306,33 @@ def refnet_forward(sd, cfg, sample, t, ehs, bank_dtype=torch.float16):
 # ----------------------------------------------------------------------------------------------
 
 
-def _vae_mid(sd, p, x):
-    x = resnet_block(sd, p + ".resnets.0", x, None, 1e-6)
+def _vae_mid(sd, p, x, tap=None):
+    tap = tap or (lambda name, x: x)
+    x = tap(p + ".resnets.0", resnet_block(sd, p + ".resnets.0", x, None, 1e-6))
     N, C, H, W = x.shape
     a = p + ".attentions.0"
     t = _gn(sd, a + ".group_norm", x.reshape(N, C, H * W), 1e-6).transpose(1, 2)
     o = mha(sd, a, t, t, 1)
-    x = o.transpose(1, 2).reshape(N, C, H, W) + x
-    return resnet_block(sd, p + ".resnets.1", x, None, 1e-6)
+    x = tap(a, o.transpose(1, 2).reshape(N, C, H, W) + x)
+    return tap(p + ".resnets.1", resnet_block(sd, p + ".resnets.1", x, None, 1e-6))
 
 
-def vae_decode(sd, cfg, z):
-    """AutoencoderKL.decode(z).sample (pipeline_pose2vid_long.py:119-120)."""
+def vae_decode(sd, cfg, z, tap=None):
+    """AutoencoderKL.decode(z).sample (pipeline_pose2vid_long.py:119-120).  tap(name, x) -> x: optional observer /
+    modifier of every block output (tests/bisect_parity.py)."""
+    tap = tap or (lambda name, x: x)
     nb = len(cfg["block_out_channels"])
     x = _conv(sd, "post_quant_conv", z, padding=0)
-    x = _conv(sd, "decoder.conv_in", x)
-    x = _vae_mid(sd, "decoder.mid_block", x)
+    x = tap("decoder.conv_in", _conv(sd, "decoder.conv_in", x))
+    x = _vae_mid(sd, "decoder.mid_block", x, tap)
     for i in range(nb):
         for j in range(cfg["layers_per_block"] + 1):
-            x = resnet_block(sd, f"decoder.up_blocks.{i}.resnets.{j}", x, None, 1e-6)
+            x = tap(f"decoder.up_blocks.{i}.resnets.{j}", resnet_block(sd, f"decoder.up_blocks.{i}.resnets.{j}", x, None, 1e-6))
         if i != nb - 1:
             x = F.interpolate(x, scale_factor=2.0, mode="nearest")
-            x = _conv(sd, f"decoder.up_blocks.{i}.upsamplers.0.conv", x)
-    x = F.silu(_gn(sd, "decoder.conv_norm_out", x, 1e-6))
-    return _conv(sd, "decoder.conv_out", x)
+            x = tap(f"decoder.up_blocks.{i}.upsamplers.0", _conv(sd, f"decoder.up_blocks.{i}.upsamplers.0.conv", x))
+    x = tap("decoder.conv_norm_out", F.silu(_gn(sd, "decoder.conv_norm_out", x, 1e-6)))
+    return tap("decoder.conv_out", _conv(sd, "decoder.conv_out", x))
 
 
 def vae_encode_mean(sd, cfg, x):

@@ -117,11 +117,75 @@ def run_size(h, f, backends, seed=0):
     return out
 
 
+@torch.no_grad()
+def run_vae(h, n, backends, seed=0):
+    """VAE decode of n latent frames (h x h): the stage that turns a 55-70 dB latent into the 46 dB frames at 512x512"""
+    from aniportrait_amd import configs as C
+    from oracle import ref_torch as O
+    from util import build_hip_models, oracle_state_dicts
+
+    cfg = C.SD_VAE_FT_MSE
+    sds = oracle_state_dicts(False, keys=["vae"])
+    g = torch.Generator().manual_seed(200 + seed)
+    z = torch.randn((n, 4, h, h), generator=g)      # ~ latents / 0.18215 after a few DDIM steps: unit scale
+    t0 = time.time()
+    want = {}
+
+    def rec(name, x):
+        want[name] = x.clone()
+        return x
+
+    O.vae_decode(sds["vae"], cfg, z, tap=rec)
+    t_oracle = time.time() - t0
+    order = list(want)
+    out = {"net": "vae_decode", "h": h, "frames": n, "tokens": h * h, "oracle_seconds": t_oracle, "blocks": order, "backends": {}}
+    for be in backends:
+        got = {}
+        t0 = time.time()
+        if be == "o16":
+            def rec16(name, x):
+                x = x.half().float()
+                got[name] = x
+                return x
+            O.vae_decode(sds["vae"], cfg, z, tap=rec16)
+        else:
+            dev = "cuda" if be == "hip" else "cpu"
+            if be == "emu":
+                import emu_hipops
+                emu_hipops.install(_Patch)
+            from aniportrait_amd import hipops as ops
+            m, _ = build_hip_models(False, keys=("vae",), device=dev)
+            x = ops.ncfhw_to_nhwc(z.unsqueeze(2).to(dev).half())          # (n, 4, 1, h, h) -> (n, h, h, 4)
+
+            def rec_nhwc(name, xx):
+                got[name] = xx.detach().float().cpu().permute(0, 3, 1, 2)
+
+            m["vae"].decode_nhwc(x, tap=rec_nhwc)
+            del m
+        rows = {name: stats(got[name].reshape(want[name].shape), want[name]) for name in order if name in got}
+        # the pipeline's metric on this stage alone: PSNR of the decoded frames in [0, 1]
+        a = (got[order[-1]].reshape(want[order[-1]].shape) / 2 + 0.5).clamp(0, 1)
+        b = (want[order[-1]] / 2 + 0.5).clamp(0, 1)
+        mse = float(((a.double() - b.double()) ** 2).mean())
+        import math
+        out["backends"][be] = {"seconds": time.time() - t0, "rows": rows, "frame_psnr_db": 10 * math.log10(1 / max(mse, 1e-30)),
+                               "saturated_fraction": float(((want[order[-1]] / 2 + 0.5 <= 0) | (want[order[-1]] / 2 + 0.5 >= 1)).float().mean())}
+        last = rows[order[-1]]
+        print(f"VAE h={h} n={n} {be:>4}: conv_out rel_rms {last['rel_rms']:.3e} rel_max {last['rel_max']:.3e} frame PSNR "
+              f"{out['backends'][be]['frame_psnr_db']:.1f} dB ({time.time() - t0:.0f} s; oracle {t_oracle:.0f} s)", flush=True)
+    return out
+
+
 def table(res):
     lines = []
     for r in res:
         bes = list(r["backends"])
-        lines.append(f"## {r['h']}x{r['h']} latents (T = {r['tokens']}), CFG batch 2 x {r['frames']} frames — rel_rms (rel_max) vs fp32 oracle")
+        if r.get("net") == "vae_decode":
+            ps = ", ".join(f"{be}: {r['backends'][be]['frame_psnr_db']:.1f} dB" for be in bes)
+            lines.append(f"## VAE decode of {r['frames']} frame(s), {r['h']}x{r['h']} latents -> {8 * r['h']}x{8 * r['h']} pixels — rel_rms "
+                         f"(rel_max) vs fp32 oracle; frame PSNR {ps}")
+        else:
+            lines.append(f"## {r['h']}x{r['h']} latents (T = {r['tokens']}), CFG batch 2 x {r['frames']} frames — rel_rms (rel_max) vs fp32 oracle")
         lines.append("| block | " + " | ".join(bes) + " |")
         lines.append("|---|" + "---|" * len(bes))
         for name in r["blocks"]:
@@ -141,13 +205,14 @@ def main():
     ap.add_argument("--backends", nargs="+", default=["emu", "o16"])
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--net", default="unet", choices=["unet", "vae"])
     a = ap.parse_args()
     if a.threads:
         torch.set_num_threads(a.threads)
     else:
         from util import oracle_threads
         oracle_threads()
-    res = [run_size(h, a.frames, a.backends) for h in a.sizes]
+    res = [(run_vae if a.net == "vae" else run_size)(h, a.frames, a.backends) for h in a.sizes]
     md = table(res)
     print(md)
     if a.out:

@@ -52,7 +52,8 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
         x = A.reshape(N_, H, Wd, Cin).float().permute(0, 3, 1, 2)
         if conv.get("upsample"):
             x = F.interpolate(x, scale_factor=2.0, mode="nearest")
-        w = W.float().reshape(W.shape[0], 3, 3, Cin).permute(0, 3, 1, 2)
+        from aniportrait_amd.hipops import unpack_conv3x3
+        w = unpack_conv3x3(W.float(), Cin, conv.get("korder", 1))
         pad = conv["pad"]
         He, We = x.shape[2], x.shape[3]
         # high-side padding implied by Hout
@@ -97,14 +98,16 @@ def ffn_geglu(x, w1p, b1p, w2, b2, residual=None):
 
 
 def conv3x3(x, Wp, bias, stride=1, pad=1, upsample=False, pad_hi=None, rowbias=None, rows_per_group=0,
-            residual=None, out_f32=False):
+            residual=None, out_f32=False, korder=None):
     N, H, Wd, Cin = x.shape
     if pad_hi is None:
         pad_hi = pad
     He, We = (2 * H, 2 * Wd) if upsample else (H, Wd)
     Ho = (He + pad + pad_hi - 3) // stride + 1
     Wo = (We + pad + pad_hi - 3) // stride + 1
-    conv = dict(Nimg=N, Hin=H, Win=Wd, Cin=Cin, Hout=Ho, Wout=Wo, stride=stride, pad=pad, upsample=upsample)
+    from aniportrait_amd.hipops import conv_korder
+    conv = dict(Nimg=N, Hin=H, Win=Wd, Cin=Cin, Hout=Ho, Wout=Wo, stride=stride, pad=pad, upsample=upsample,
+                korder=conv_korder(Cin) if korder is None else korder)
     res2 = residual.reshape(-1, Wp.shape[0]) if residual is not None else None
     out = gemm(x, Wp, bias, rowbias=rowbias, rows_per_group=rows_per_group, residual=res2, conv=conv,
                out_f32=out_f32)

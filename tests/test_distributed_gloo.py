@@ -160,3 +160,82 @@ def test_two_rank_long_clip_pipeline_matches_reference(case, L):
         assert p.exitcode == 0
     assert res[0][0] == 0 and res[0][1] >= 40.0 and res[0][2] == (1, 3, L, 128, 128), res
     assert res[1][0] == 1 and res[1][1] is True, res
+
+
+def _long_clip_inputs():
+    """L = 78 at 64x64 with 8-frame windows overlapping by 2: 13 windows per DDIM step (the window count of BASELINE
+    configs[3]: L = 150, 16-frame windows), the last one wrapping around the clip end, offsets moving with the step"""
+    from aniportrait_amd.synthetic import synth_latents, synth_pose_frames, synth_ref_image
+    H = W = 64
+    L = 78
+    return dict(H=H, W=W, L=L, steps=2, cfg=3.5, kw=dict(context_frames=8, context_overlap=2),
+                poses=synth_pose_frames(L, H, W), ref_pose=synth_pose_frames(1, H, W, 999)[0],
+                ref_image=synth_ref_image(H, W), latents=synth_latents(L, H // 8, W // 8, 42))
+
+
+def _run_long_clip(dp_group=None):
+    from aniportrait_amd import configs as C
+    from aniportrait_amd.scheduling_ddim import DDIMScheduler
+    from src.pipelines.pipeline_pose2vid_long import Pose2VideoPipeline
+    from util import build_hip_models, small_clip_encoder
+    m, _ = build_hip_models(True, device="cpu")
+    i = _long_clip_inputs()
+    pipe = Pose2VideoPipeline(vae=m["vae"], image_encoder=small_clip_encoder("cpu"), reference_unet=m["reference_unet"],
+                              denoising_unet=m["denoising_unet"], pose_guider=m["pose_guider"],
+                              scheduler=DDIMScheduler(**C.DDIM_V2))
+    pipe.set_progress_bar_config(disable=True)
+    kw = dict(i["kw"])
+    if dp_group is not None:
+        kw["dp_group"] = dp_group
+    return pipe(i["ref_image"], list(i["poses"]), i["ref_pose"], i["W"], i["H"], i["L"], i["steps"], i["cfg"],
+                latents=i["latents"], **kw)
+
+
+def _eight_rank_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [here, os.path.dirname(here)]
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import emu_hipops
+        emu_hipops.install(_Patch())
+        out = _run_long_clip(dist.group.WORLD)
+        q.put((rank, None if out is None else out.videos))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.slow
+def test_eight_rank_long_clip_equals_single_process_bit_for_bit(monkeypatch):
+    """BASELINE configs[3]'s sharding on the rank count it is meant for: ONE long clip, 13 windows per step dealt to 8
+    ranks (`shard_balanced`: five ranks run two windows, three run one), rank 0's ReferenceNet banks broadcast, one
+    in-place all-reduce of the window sums per step, 78 frames decoded 10 / 10 / ... / 9 per rank and gathered
+    point-to-point with uneven shares — 8 gloo processes on the kernel emulator.  Every frame is covered by at most two
+    windows, so its window sum has at most two non-zero terms and the all-reduce order cannot change it: the video on
+    rank 0 must EQUAL the single-process result bit for bit."""
+    import emu_hipops
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eight_rank_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    emu_hipops.install(monkeypatch)
+    ref = _run_long_clip(None).videos          # world size 1, in this process, while the workers run
+    res = dict(q.get(timeout=1500) for _ in range(world))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(res[r] is None for r in range(1, world))
+    got = res[0]
+    assert tuple(got.shape) == tuple(ref.shape) == (1, 3, 78, 64, 64)
+    assert torch.isfinite(got).all() and float(got.std()) > 1e-3
+    assert torch.equal(got, ref), f"8-rank video differs from world size 1: max |d| = {float((got - ref).abs().max()):.3e}"
+    # the sharding the run used: every window owned exactly once, no rank with more than two
+    from aniportrait_amd import distributed as D
+    parts = D.shard_balanced([8] * 13, world)
+    assert sorted(sum(parts, [])) == list(range(13)) and max(len(p_) for p_ in parts) == 2 and min(len(p_) for p_ in parts) == 1

@@ -77,3 +77,56 @@ def test_missing_blob_is_reported(tmp_path):
     from src.utils.frame_interpolation import init_frame_interpolation_model     # the drop-in import path
     with pytest.raises(FileNotFoundError):
         init_frame_interpolation_model(str(tmp_path / "film_net_fp16.pt"))
+
+
+def _pairwise_order_on_device(x, model, inter_frames, device):
+    """TEST-SIDE restatement of the reference's loop structure (src/utils/frame_interpolation.py:22-68) for the GPU box,
+    where the reference checkout does not exist: pair by pair, batch 1, fp32 CPU frames -> `.half().cuda()` -> model ->
+    `.clamp(0, 1).cpu().float()`, insertion order recomputed per pair with the reference's own formulas.  (On the CPU
+    the product is compared with the reference's real function above.)"""
+    import bisect
+
+    import numpy as np
+    out = []
+    for idx in range(x.shape[2] - 1):
+        results = [x[:, :, idx], x[:, :, idx + 1]]
+        n = int(inter_frames)
+        idxes, remains = [0, n + 1], list(range(1, n + 1))
+        splits = torch.linspace(0, 1, n + 2)
+        for _ in range(n):
+            starts, ends = splits[idxes[:-1]], splits[idxes[1:]]
+            distances = ((splits[None, remains] - starts[:, None]) / (ends[:, None] - starts[:, None]) - .5).abs()
+            start_i, step = np.unravel_index(torch.argmin(distances).item(), distances.shape)
+            end_i = start_i + 1
+            x0, x1 = results[start_i].half().to(device), results[end_i].half().to(device)
+            dt = x0.new_full((1, 1), (splits[remains[step]] - splits[idxes[start_i]])) / (splits[idxes[end_i]] - splits[idxes[start_i]])
+            with torch.no_grad():
+                pred = model(x0, x1, dt)
+            pos = bisect.bisect_left(idxes, remains[step])
+            idxes.insert(pos, remains[step])
+            results.insert(pos, pred.clamp(0, 1).cpu().float())
+            del remains[step]
+        out += [r.unsqueeze(2) for r in results[:-1]]
+    out.append(x[:, :, -1].unsqueeze(2))
+    return torch.cat(out, dim=2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("inter_frames,pair_chunk", [(1, 16), (2, 3), (3, None)])
+def test_device_resident_batched_interpolation_on_the_gpu(inter_frames, pair_chunk):
+    """f3 on the MI355X: the clip uploaded once, the stand-in model in fp16 on `cuda`, one model call per insertion step
+    on (chunks of) the batch of all frame pairs, result on the host or left on the device (`output_device`) — bit-equal
+    to the pairwise, batch-1, transfer-per-call order of the reference's loop"""
+    from aniportrait_amd.frame_interpolation import batch_images_interpolation_tool
+    dev = torch.device("cuda")
+    model = FakeFilm().half().to(dev)
+    x = _clip(bs=2, F=9, H=64, W=48, seed=3 + inter_frames)
+    want = _pairwise_order_on_device(x, model, inter_frames, dev)
+    got = batch_images_interpolation_tool(x, model, inter_frames=inter_frames, pair_chunk=pair_chunk)
+    assert got.device.type == "cpu" and got.dtype == torch.float32
+    assert got.shape == want.shape == (2, 3, 8 * (inter_frames + 1) + 1, 64, 48)
+    assert torch.equal(got, want)
+    on_dev = batch_images_interpolation_tool(x.to(dev), model, inter_frames=inter_frames, pair_chunk=pair_chunk,
+                                             output_device=dev)
+    assert on_dev.is_cuda and torch.equal(on_dev.cpu(), want)
+    assert torch.equal(got[:, :, ::inter_frames + 1], x)          # the given frames come through untouched, in fp32
