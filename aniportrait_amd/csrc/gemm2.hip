@@ -510,11 +510,12 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
   const int tsel = fq & 1, csel = (fq >> 1) * 8;   // after row_swap: tile of the pair / column offset in it
 
   // 8 consecutive output columns [n, n+8) of row m: bias / row-group bias / residual / store
-  auto emit8 = [&](int m, int n, int ncols, float (&v)[8], bool with_bias) {
+  // (add_bias / add_rb: false when the accumulators were started from that term — acc_has_bias / rb_uni above)
+  auto emit8 = [&](int m, int n, int ncols, float (&v)[8], bool add_bias, bool add_rb, bool add_res) {
     if (m >= p.M) return;
     const int nvalid = min(8, ncols - n);
     if (nvalid <= 0) return;
-    if (with_bias && p.bias != nullptr) {
+    if (add_bias && p.bias != nullptr) {
       if (nvalid == 8) {
         const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 4);
         v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
           if (e < nvalid) v[e] += p.bias[n + e];
       }
     }
-    if (with_bias && p.rowbias != nullptr) {
+    if (add_rb && p.rowbias != nullptr) {
       const float* rbp = p.rowbias + ((int64_t)m / p.rows_per_group) * p.ld_rowbias + n;
       if (nvalid == 8 && ((p.ld_rowbias & 3) == 0) && (((uintptr_t)p.rowbias & 15) == 0)) {
         const float4 b0 = *(const float4*)rbp, b1 = *(const float4*)(rbp + 4);
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
           if (e < nvalid) v[e] += rbp[e];
       }
     }
-    if (with_bias && p.residual != nullptr) {
+    if (add_res && p.residual != nullptr) {
       const f16* rp = (const f16*)p.residual + (int64_t)m * p.ldr + n;
       if (nvalid == 8 && ((p.ldr & 7) == 0)) {
         U4H8 t;
@@ -578,15 +579,15 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
     }
   };
   // 4 consecutive output columns (the unpaired last tile when BN/32 is odd)
-  auto emit4 = [&](int m, int n, float (&v)[4]) {
+  auto emit4 = [&](int m, int n, float (&v)[4], bool add_bias, bool add_rb) {
     if (m >= p.M) return;
     const int nvalid = min(4, p.N - n);
     if (nvalid <= 0) return;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (e < nvalid) {
-        if (p.bias != nullptr) v[e] += p.bias[n + e];
-        if (p.rowbias != nullptr) v[e] += p.rowbias[((int64_t)m / p.rows_per_group) * p.ld_rowbias + n + e];
+        if (add_bias && p.bias != nullptr) v[e] += p.bias[n + e];
+        if (add_rb && p.rowbias != nullptr) v[e] += p.rowbias[((int64_t)m / p.rows_per_group) * p.ld_rowbias + n + e];
       }
     }
     if (p.residual != nullptr) {
@@ -693,19 +694,27 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
           v[r] = h0;
           v[4 + r] = h1;
         }
-        emit8(m0 + wm * WTM + i * 16 + fr, ocol, p.N / 2, v, false);
+        emit8(m0 + wm * WTM + i * 16 + fr, ocol, p.N / 2, v, false, false, false);
       }
     }
   } else {
     // A block whose tile lies fully inside the output and whose operands allow 16-B accesses (every hot shape of the
     // path) takes the tight epilogue below; ragged tiles take the general per-element-guarded one.
     const bool has_rb = p.rowbias != nullptr, has_res = p.residual != nullptr;
+    // (32-bit per-lane byte offsets: the output / residual extents must stay below 4 GiB)
     const bool tight = !(dbg & 8) && p.alpha == 1.0f && m0 + BM2 <= p.M && n0 + BN <= p.N &&
                        (p.out_f32 ? (p.ldo & 3) == 0 : ((p.head_dim > 0 ? p.head_dim : p.ldo) & 7) == 0) &&
                        (!has_res || (p.ldr & 7) == 0) &&
                        (acc_has_bias || (p.bias == nullptr && !has_rb)) &&
-                       (int64_t)p.M * p.ldo * 4 < (1ll << 32) && (!has_res || (int64_t)p.M * p.ldr * 2 < (1ll << 32));
+                       (int64_t)p.M * p.ldo * (p.out_f32 ? 4 : 2) < (1ll << 32) &&
+                       (!has_res || (int64_t)p.M * p.ldr * 2 < (1ll << 32));
     if (!tight) {
+      // general path.  The accumulators may ALREADY hold the bias (and a block-uniform row-group bias): a full tile with
+      // 16-B accessible bias terms takes `acc_has_bias` whether or not the rest of the tight conditions hold (output of
+      // 4 GiB or more, unaligned leading dimensions).  Round 2 added them a second time here — the decoded frames of a
+      // 16-frame VAE batch at 512x512 / 768x768 (2^30+ output elements in the upsampler convs) carried every channel's
+      // bias twice: the "46 dB at 512x512, 38 dB at 768x768" of the round-2 / round-3 parity runs.
+      const bool add_bias = !acc_has_bias, add_rb = !(acc_has_bias && rb_uni);
 #pragma unroll
       for (int jp = 0; jp < NB / 2; ++jp) {
         const int n = n0 + tile_c(2 * jp) + tsel * 16 + csel;
@@ -719,7 +728,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
             v[r] = x;
             v[4 + r] = y;
           }
-          emit8(m0 + wm * WTM + i * 16 + fr, n, p.N, v, true);
+          emit8(m0 + wm * WTM + i * 16 + fr, n, p.N, v, add_bias, add_rb, true);
         }
       }
       if (NB & 1) {
@@ -729,7 +738,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
           float v[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = acc[i][NB - 1][r] * alpha;
-          emit4(m0 + wm * WTM + i * 16 + fr, n, v);
+          emit4(m0 + wm * WTM + i * 16 + fr, n, v, add_bias, add_rb);
         }
       }
     } else {

@@ -176,6 +176,39 @@ def run_vae(h, n, backends, seed=0):
     return out
 
 
+@torch.no_grad()
+def run_vae_batch(h, n, backends, seed=0):
+    """frames are independent in the VAE decode: a batch of n frames must reproduce the n single-frame decodes block by
+    block.  `hip` only (no oracle involved); rows: batched vs one-by-one outputs of frames 0 and n-1."""
+    from aniportrait_amd import hipops as ops
+    from util import build_hip_models
+    g = torch.Generator().manual_seed(300 + seed)
+    z = (torch.randn((n, 4, h, h), generator=g) * 5.0)
+    m, _ = build_hip_models(False, keys=("vae",), device="cuda")
+    x = ops.ncfhw_to_nhwc(z.unsqueeze(2).cuda().half())
+    order, batch, single = [], {}, {}
+
+    def rec_b(name, xx):
+        order.append(name)
+        batch[name] = xx[[0, n - 1]].detach().float().cpu()
+
+    m["vae"].decode_nhwc(x, tap=rec_b)
+    for k, fi in enumerate((0, n - 1)):
+        def rec_s(name, xx, k=k):
+            single.setdefault(name, [None, None])[k] = xx[0].detach().float().cpu()
+        m["vae"].decode_nhwc(x[fi:fi + 1].contiguous(), tap=rec_s)
+    rows = {name: stats(batch[name], torch.stack(single[name])) for name in order}
+    a = (batch[order[-1]] / 2 + 0.5).clamp(0, 1)
+    b = (torch.stack(single[order[-1]]) / 2 + 0.5).clamp(0, 1)
+    mse = float(((a.double() - b.double()) ** 2).mean())
+    import math
+    ps = float("inf") if mse == 0 else 10 * math.log10(1 / mse)
+    print(f"VAE batch-vs-single h={h} n={n}: frame PSNR {ps:.1f} dB; first differing block: "
+          f"{next((nm for nm in order if rows[nm]['rel_max'] > 0), None)}", flush=True)
+    return {"net": "vae_decode", "h": h, "frames": n, "tokens": h * h, "oracle_seconds": 0.0, "blocks": order,
+            "backends": {"hip batch vs hip single": {"seconds": 0.0, "rows": rows, "frame_psnr_db": ps}}}
+
+
 def table(res):
     lines = []
     for r in res:
@@ -205,14 +238,15 @@ def main():
     ap.add_argument("--backends", nargs="+", default=["emu", "o16"])
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--out", default=None)
-    ap.add_argument("--net", default="unet", choices=["unet", "vae"])
+    ap.add_argument("--net", default="unet", choices=["unet", "vae", "vaebatch"])
     a = ap.parse_args()
     if a.threads:
         torch.set_num_threads(a.threads)
     else:
         from util import oracle_threads
         oracle_threads()
-    res = [(run_vae if a.net == "vae" else run_size)(h, a.frames, a.backends) for h in a.sizes]
+    fn = {"vae": run_vae, "vaebatch": run_vae_batch, "unet": run_size}[a.net]
+    res = [fn(h, a.frames, a.backends) for h in a.sizes]
     md = table(res)
     print(md)
     if a.out:

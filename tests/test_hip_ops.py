@@ -792,3 +792,39 @@ def test_gemm2_wide_conv3x3(N, H, W, Cin, Cout, stride, pad, pad_hi, up):
         out2 = ops.conv3x3(x, wp, b.to(DEV), rowbias=temb, rows_per_group=rpg, residual=res)
         idx = (torch.arange(out.numel() // Cout) // rpg).reshape(out.shape[:3])
         close(out2, ref.cpu() + temb.cpu()[idx] + res.float().cpu(), "gemm2 wide conv3x3 + temb rowbias + residual")
+
+
+def test_gemm2_bias_is_added_once_on_the_general_epilogue_path():
+    """full tiles start their accumulators from the bias; the general (non-"tight") epilogue must not add it again.
+    Two ways into that combination: a leading dimension that rules out 16-B stores (N = 648 -> ldo % 8 != 0 ... here
+    N = 652), and an output of 2^30 elements or more (32-bit byte offsets no longer fit) — the VAE's upsampler convs on a
+    16-frame batch at 512x512, where round 2 added every channel's bias twice (C2 parity 46 dB instead of 60+)."""
+    ops = _ops()
+    M, N, K = 40960, 652, 320
+    A = rnd(M, K, seed=301).to(DEV)
+    W = rnd(N, K, seed=302, scale=K ** -0.5).to(DEV)
+    bias = (rnd(N, seed=303).float() * 3 + 5).to(DEV)            # a bias that cannot hide in the tolerance
+    rowbias = rnd(5, N, seed=304).float().to(DEV)
+    res = rnd(M, N, seed=305).to(DEV)
+    ref = _ref_mm_gpu(A, W) + bias.cpu() + rowbias.cpu().repeat_interleave(8192, dim=0) + res.float().cpu()
+    close(ops.gemm(A, W, bias, rowbias=rowbias, rows_per_group=8192, residual=res), ref, "gemm2 unaligned ldo, bias + rowbias + res")
+    # 2^30 output elements: M = 4 Mi rows x 256 columns (fp16 out = 2 GiB), short K
+    M, N, K = 1 << 22, 256, 64
+    A = rnd(4096, K, seed=306).to(DEV).repeat(M // 4096, 1)
+    W = rnd(N, K, seed=307, scale=K ** -0.5).to(DEV)
+    bias = (rnd(N, seed=308).float() * 3 + 5).to(DEV)
+    out = ops.gemm(A, W, bias)
+    ref = (_ref_mm_gpu(A[:4096], W) + bias.cpu())
+    for r0 in (0, M // 2, M - 4096):
+        close(out[r0:r0 + 4096], ref, f"gemm2 2^30-element output rows {r0}..")
+    del out
+    x = rnd(4, 64, 64, 64, seed=309).to(DEV).repeat(4, 4, 4, 1)       # (16, 256, 256, 64) -> upsampled conv, 2^30 outputs
+    w = rnd(256, 64, 3, 3, seed=310, scale=(9 * 64) ** -0.5)
+    b = (rnd(256, seed=311).float() * 3 + 5)
+    y = ops.conv3x3(x, ops.pack_conv3x3(w).to(DEV), b.to(DEV), upsample=True)
+    ref = F.conv2d(F.interpolate(x[:1].float().permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest"), w.float().to(DEV),
+                   b.to(DEV), padding=1).permute(0, 2, 3, 1)
+    # interior of image 0 and of the last image (same content as image 3 of the 4-image base pattern is NOT image 0:
+    # compare image 0 only, and the bias-dominated mean of the last image)
+    close(y[0, 8:-8, 8:-8], ref[0, 8:-8, 8:-8], "conv3x3 upsample, 2^30-element output, image 0")
+    assert abs(float(y[-1].float().mean()) - float(y[0].float().mean())) < 0.5

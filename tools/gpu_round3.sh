@@ -44,6 +44,16 @@ PY
     N=${STEP#ktests:}
     timeout 900 python -m pytest tests/test_hip_ops.py -m gpu -q -k "gemm or conv3x3 or ffn" > $OUT/ktests_$N.log 2>&1; echo "rc=$?" >> $OUT/ktests_$N.log
     grep -E "^FAILED|^ERROR|passed|failed|rc=" $OUT/ktests_$N.log | tail -n 25 ;;
+  vaebatch)
+    timeout 600 python tests/bisect_parity.py --net vaebatch --sizes 32 64 96 --frames 16 --backends hip --out $OUT/vae_batch_vs_single.json > $OUT/vae_batch_vs_single.log 2>&1; echo "rc=$?" >> $OUT/vae_batch_vs_single.log
+    grep -E "VAE batch|rc=|Error" $OUT/vae_batch_vs_single.log | tail -n 8
+    python - <<PY
+import json
+for r in json.load(open("$OUT/vae_batch_vs_single.json")):
+    rows=list(r["backends"].values())[0]["rows"]
+    print("h=%d:"%r["h"], [(k.replace("decoder.",""), "%.1e"%v["rel_max"]) for k,v in rows.items() if v["rel_max"]>0][:6])
+PY
+    ;;
   bisectvae)
     timeout 900 python tests/bisect_parity.py --net vae --sizes 16 32 64 96 --frames 1 --backends hip --out $OUT/bisect_vae_hip.json > $OUT/bisect_vae_hip.log 2>&1; echo "rc=$?" >> $OUT/bisect_vae_hip.log
     grep -E "VAE h|rc=" $OUT/bisect_vae_hip.log | tail -n 8 ;;
