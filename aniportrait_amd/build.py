@@ -31,7 +31,12 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, extra_flags=(), lib=None):
+    """extra_flags / lib: experiment builds (e.g. -DANIP_GEMM2_TIMING into lib/libaniportrait_hip_timing.so, loaded with
+    ANIP_LIB=<path>); the product is always the flag-less default."""
+    global LIB
+    if lib is not None:
+        LIB, force = lib, True
     if not force and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
@@ -39,8 +44,8 @@ def build(force=False, verbose=True):
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
-        cmd = [cc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c",
+        obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + (".x.o" if extra_flags else ".o"))
+        cmd = [cc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", *extra_flags, "-x", "hip", "-c",
                os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -62,4 +67,6 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    flags = [a for a in sys.argv[1:] if a.startswith("-D")]
+    out = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--out=")), None)
+    print(build(force="--force" in sys.argv, extra_flags=flags, lib=os.path.join(LIBDIR, out) if out else None))

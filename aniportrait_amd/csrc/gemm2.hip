@@ -156,20 +156,17 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
       const int img = mm / hw, rem = mm - img * hw;
       const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
       const int y0 = oy * p.stride - p.pad, x0 = ox * p.stride - p.pad;
-      if (p.upsample) {
-        a_v0[i] = okm ? (uint32_t)img * (uint32_t)(p.Hin * p.Win) : 0xFFFFFFFFu;
-        a_v1[i] = ((uint32_t)(y0 + 1) << 16) | (uint32_t)(x0 + 1);
-      } else {
-        uint32_t mask = 0;
+      uint32_t mask = 0;
 #pragma unroll
-        for (int t9 = 0; t9 < 9; ++t9) {
-          const int y = y0 + t9 / 3, x = x0 + t9 % 3;
-          if (okm && y >= 0 && y < p.Hin && x >= 0 && x < p.Win) mask |= 1u << t9;
-        }
-        a_v0[i] = (((uint32_t)img * (uint32_t)(p.Hin * p.Win) + (uint32_t)(oy * p.stride * p.Win + ox * p.stride)) * (uint32_t)p.Cin +
-                   (uint32_t)(g * 8)) * 2u;
-        a_v1[i] = mask;
+      for (int t9 = 0; t9 < 9; ++t9) {
+        const int y = y0 + t9 / 3, x = x0 + t9 % 3;
+        mask |= (okm && y >= 0 && y < p.Hin && x >= 0 && x < p.Win) ? (1u << t9) : 0u;
       }
+      const uint32_t pix0 = (uint32_t)img * (uint32_t)(p.Hin * p.Win);
+      const uint32_t centre = ((pix0 + (uint32_t)(oy * p.stride * p.Win + ox * p.stride)) * (uint32_t)p.Cin + (uint32_t)(g * 8)) * 2u;
+      const bool ups = p.upsample != 0;
+      a_v0[i] = ups ? (okm ? pix0 : 0xFFFFFFFFu) : centre;
+      a_v1[i] = ups ? (((uint32_t)(y0 + 1) << 16) | (uint32_t)(x0 + 1)) : mask;
     } else {
       a_v0[i] = okm ? (uint32_t)(((int64_t)m * p.lda + g * 8) * 2) : OOB;
       a_v1[i] = (okm && p.A2 != nullptr) ? (uint32_t)(((int64_t)m * p.lda2 + g * 8) * 2) : OOB;
@@ -301,7 +298,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
     nk = max(0, min(nk - kt_begin, per));
   }
   constexpr bool PHASED = (NST == 2 && KH == 2 && NW == 8);
-  if constexpr (PHASED && SCHED == 1) {
+  if constexpr (PHASED && SCHED >= 1) {
     // Quarter-phased schedule (round 3).  Round 2's role-alternating loop below issues the WHOLE next K-tile (8-9 LDS-DMA
     // instructions per wave, 36 KiB per wave group through the CU's one 64 B/clk address path) inside ONE of its four
     // load segments per K-tile and drains it (vmcnt(0)) once per K-tile: that segment is ~3x longer than the 32-MFMA
@@ -309,106 +306,252 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
     // Here a K-tile is FOUR sub-steps of 4 x NB MFMAs (a wave's 128 x WTN tile as [A-lo | A-hi] x [k-half 0 | 1]), the
     // next tile's DMA is dealt over the four load segments — B first half, B second half, A-lo, A-hi: 2-3 instructions
     // each — and the queue is never drained: counted vmcnt at two points per tile,
-    //   sub-step order   j=0: A-lo x B(kh0)   j=1: A-lo x B(kh1)   j=2: A-hi x B(kh1)   j=3: A-hi x B(kh0)
-    //   LOAD(j) reads    bf0, af               bf1, af               af                   af        (bf0 / bf1 stay live)
-    //   LOAD(j) stages   B[0:half) of t+1      B[half:) of t+1       A-lo of t+1          A-hi of t+1
-    //   wait before bar  lgkm                  vmcnt(NB_I): A-hi(t)  lgkm                 vmcnt(2): all of t+1 but A-hi
-    // A-hi of tile t+1, staged last, is first read at j=2 of tile t+1 and waited for at the end of LOAD(j=1) there: four
-    // segments to land.  Waves 4-7 run one barrier behind waves 0-3 as before (a wave's compute segment coincides with
-    // its SIMD partner's load segment).  Hazards, with barrier #b closing interval I(b); group 0 runs LOAD(s) in I(2s)
-    // and COMPUTE(s) in I(2s+1), group 1 LOAD(s) in I(2s+1), COMPUTE(s) in I(2s+2), s = 4t + j:
+    //   sub-step order   j=0: A-lo x B(kh0)   j=1: A-hi x B(kh0)   j=2: A-hi x B(kh1)   j=3: A-lo x B(kh1)
+    //   LOAD(j) reads    bf, af                af                    bf (replaced), af    af         (ONE set of B registers)
+    //   LOAD(j) stages   B blocks 0,1 of t+1   B blocks 2.. of t+1   A-lo of t+1          A-hi of t+1      (per wave)
+    //   wait before bar  vmcnt(2): A-hi(t)     lgkm                  lgkm                 vmcnt(2): all of t+1 but A-hi
+    // A-hi of tile t+1, staged last, is first read at j=1 of tile t+1 and waited for at the end of LOAD(j=0) there.
+    // Waves 4-7 run one barrier behind waves 0-3 as before (a wave's compute segment coincides with its SIMD partner's
+    // load segment).  Hazards, with barrier #b closing interval I(b); group 0 runs LOAD(s) in I(2s) and COMPUTE(s) in
+    // I(2s+1), group 1 LOAD(s) in I(2s+1), COMPUTE(s) in I(2s+2), s = 4t + j:
     //   RAW  every wave waits for its own DMA share before a barrier that every reader passes before it reads: the
     //        j=3 wait of tile t is before #8t+6 (group 0) / #8t+7 (group 1), the first reads of tile t+1 come after
-    //        #8t+7 / #8t+8; the j=1 wait before #8t+2 / #8t+3, the A-hi reads after #8t+3 / #8t+4.
-    //   WAR  a region of the other stage is re-staged in tile t at the sub-step AFTER the one that last read it in tile
-    //        t-1 (B: j=0/1, read last at j=1; A-lo: j=2, read last at j=1; A-hi: j=3, read last at j=3 of t-1, i.e. four
-    //        segments earlier), and every LOAD ends with lgkmcnt(0) before its barrier.
+    //        #8t+7 / #8t+8; the j=0 wait of tile t+1 before #8t+8 / #8t+9, the A-hi reads after #8t+9 / #8t+10.
+    //   WAR  a region of the other stage is re-staged in tile t no earlier than the sub-step that last read it in tile
+    //        t-1 (B: from j=0, read last at j=2; A-lo: j=2, read last at j=3; A-hi: j=3, read last at j=2) — a whole
+    //        K-tile later, and every LOAD ends with lgkmcnt(0) before its barrier.
+    // (First version of this loop: both B fragment sets live, A-hi needed only at j=2.  The 256 x 320 convolution kernel
+    // then sits at 253-256 VGPRs and any extra state spills INTO the loop: 3x slower, profiles/r03/h_*.)
     static_assert(FM == 8 && NA_I == 4 && NB_TOT % NW == 0, "quarter-phased schedule: 256-row tile, 2 x 4 waves");
-    constexpr int HALF_B = NB_TOT / 2;
-    // B instruction i of this wave fills row block wave + NW * i: first half of B?  (a constant after unrolling except
-    // for the one i whose blocks straddle the middle: BN = 320, i = 2)
-    auto b_first = [&](int i) -> bool {
-      return (NW * i + NW - 1 < HALF_B) ? true : ((NW * i >= HALF_B) ? false : (wave + NW * i < HALF_B));
+    // DMA operands of the NEXT K-tile are PREPARED inside a compute segment (scalar / vector address arithmetic hides
+    // between the MFMAs) so that a load segment carries only the bare `buffer_load ... lds` instructions: with the
+    // arithmetic inside the load segments those ran 45-126 non-memory instructions each (conv: tap decode, window test,
+    // per-lane select; plain: source select, K-tail test), longer than the 16-20 MFMAs of the partner they hide behind.
+    // Prepared state is SCALAR only (the per-lane part of an A offset is 2-4 VALU operations at the point of issue):
+    //   conv    p_tap (window tap), p_delta (byte offset of (tap, first channel) relative to the window's centre pixel)
+    //   plain   pa_second (second A source), pa_soff (byte offset of the K position inside the source row)
+    //   pb_soff byte offset of the K-tile inside a W row;  p_ktail: the tile crosses K (per-lane K-tail tests, rare)
+    uint32_t pa_soff = 0, pb_soff = 0;
+    int p_tap = 0, p_delta = 0, p_c0 = 0;
+    bool pa_second = false, p_ktail = false;
+    // conv K cursor of the tile to prepare next (no division in the loop): tap, first channel
+    int cv_tap = 0, cv_c0 = 0;
+    if (CONV) {
+      const int k1 = (kt_begin + 1) * BKT;
+      if (p.conv == 2) {
+        const int cb = k1 / 576, r = k1 - cb * 576;
+        cv_tap = r >> 6;
+        cv_c0 = cb * 64 + (r & 63);
+      } else {
+        cv_tap = k1 / p.Cin;
+        cv_c0 = k1 - cv_tap * p.Cin;
+      }
+    }
+    // conv, K order 2, no upsample (every hot conv): the byte delta of the K-tile's (tap, channel block) relative to the
+    // window's centre pixel advances by one of three constants per K-tile — next tap in the row, next row, next channel
+    // block — so that `prepare` is a handful of scalar adds (round 3's first version recomputed it with divisions and
+    // multiplies from the kernel arguments: 400 cycles behind the MFMAs of every fourth compute segment).
+    const bool cv_fast = CONV && p.conv == 2 && !p.upsample && BKT == 64;
+    int cv_delta = 0;                                                     // delta of the tile to prepare next
+    if (cv_fast) {
+      const int dy = cv_tap / 3, dx = cv_tap - dy * 3;
+      cv_delta = (((dy - p.pad) * p.Win + (dx - p.pad)) * p.Cin + cv_c0) * 2;
+    }
+    auto prepare = [&](int kt) {
+      const int k0 = kt * BKT;
+      p_ktail = k0 + BKT > p.K;
+      pb_soff = (uint32_t)k0 * 2u;
+      if (CONV) {
+        p_tap = cv_tap;
+        p_c0 = cv_c0;
+        if (cv_fast) {
+          p_delta = cv_delta;
+          const bool row_end = cv_tap == 2 || cv_tap == 5;
+          const bool blk_end = cv_tap == 8;
+          const int stepx = p.Cin * 2;                          // tap + 1 inside a row
+          cv_delta += blk_end ? 128 - (2 * p.Win + 2) * stepx   // tap 8 -> tap 0 of the next 64-channel block
+                              : (row_end ? (p.Win - 2) * stepx : stepx);   // tap 2 -> 3, 5 -> 6 / next tap
+          cv_tap = blk_end ? 0 : cv_tap + 1;
+        } else {
+          const int dy = p_tap / 3, dx = p_tap - dy * 3;
+          p_delta = (((dy - p.pad) * p.Win + (dx - p.pad)) * p.Cin + p_c0) * 2;
+          // advance the cursor by one K-tile — value selects only: conditional stores to the two cursor variables get
+          // merged by the compiler into one store through a selected POINTER, which puts them in scratch memory
+          const int c = cv_c0 + BKT;
+          const bool blk = p.conv == 2 ? ((c & 63) == 0) : (c >= p.Cin);   // left the channel block / the tap
+          const int tap1 = cv_tap + (blk ? 1 : 0);
+          const bool wrap9 = p.conv == 2 && tap1 == 9;                       // conv = 2: next 64-channel block
+          cv_tap = wrap9 ? 0 : tap1;
+          cv_c0 = p.conv == 2 ? ((blk && !wrap9) ? c - 64 : c) : (blk ? 0 : c);
+        }
+      } else {
+        pa_second = (p.A2 != nullptr) && (k0 >= p.K1);   // wave-uniform (K1 % BKT == 0)
+        pa_soff = (uint32_t)(pa_second ? k0 - p.K1 : k0) * 2u;
+      }
+    };
+    auto fire_a = [&](int stage, int i) {
+      char* dst = smem + stage * STAGE + a_blk(i) * 1024;
+      if (CONV) {
+        uint32_t vo;
+        if (p.upsample) {                    // 3 convs per UNet call: round 2's per-issue arithmetic
+          const int dy = p_tap / 3, dx = p_tap - dy * 3;
+          int y = (int)(a_v1[i] >> 16) - 1 + dy, x = (int)(a_v1[i] & 0xFFFFu) - 1 + dx;
+          const bool ok = a_v0[i] != 0xFFFFFFFFu && y >= 0 && y < 2 * p.Hin && x >= 0 && x < 2 * p.Win;
+          y >>= 1; x >>= 1;
+          vo = ok ? ((a_v0[i] + (uint32_t)(y * p.Win + x)) * (uint32_t)p.Cin + (uint32_t)(p_c0 + a_g[i] * 8)) * 2u : OOB;
+        } else {
+          vo = ((a_v1[i] >> p_tap) & 1u) ? a_v0[i] + (uint32_t)p_delta : OOB;
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(dst), 16, vo, 0, 0, 0);
+      } else {
+        uint32_t vo = pa_second ? a_v1[i] : a_v0[i];
+        if (p_ktail) {                       // rare: K % 64 != 0, last tile only
+          const int klim = pa_second ? p.K - p.K1 : (p.A2 ? p.K1 : p.K);
+          if ((int)(pa_soff >> 1) + a_g[i] * 8 >= klim) vo = OOB;
+        }
+        if (pa_second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA2, LDS_PTR(dst), 16, vo, pa_soff, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(dst), 16, vo, pa_soff, 0, 0);
+      }
+    };
+    auto fire_b = [&](int stage, int i) {
+      uint32_t vo = b_off[i];
+      if (p_ktail) {                         // rare: K % 64 != 0, last tile only
+        const int row = (wave + NW * i) * RPI + lr;
+        if ((int)(pb_soff >> 1) + (ls ^ swz_of<BKT>(row)) * 8 >= p.K) vo = OOB;
+      }
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(smem + stage * STAGE + A_BYTES + (wave + NW * i) * 1024), 16, vo, pb_soff, 0, 0);
     };
     const int grp = wave >> 2;
     if (nk > 0) issue(kt_begin, 0);
+    if (CONV && nk > 1) prepare(kt_begin + 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (grp == 1) __builtin_amdgcn_s_barrier();
-    f16x8 bf0[NB], bf1[NB], af[4];
+    f16x8 bf[NB], af[4];
     const int a_lo = a_row_off, a_hi = a_row_off + 64 * RB;
 #define ANIP_G2_BAR()                      \
     __builtin_amdgcn_sched_barrier(0);     \
     __builtin_amdgcn_s_barrier();          \
     __builtin_amdgcn_sched_barrier(0)
-#define ANIP_G2_MMA(I0, BF)                                                                               \
+#define ANIP_G2_MMA(I0)                                                                                   \
     __builtin_amdgcn_s_setprio(1);                                                                        \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < NB; ++j)          \
-        acc[(I0) + i][j] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], BF[j], acc[(I0) + i][j], 0, 0, 0) \
-                                 : __builtin_amdgcn_mfma_f32_16x16x32_f16(BF[j], af[i], acc[(I0) + i][j], 0, 0, 0); \
+        acc[(I0) + i][j] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[(I0) + i][j], 0, 0, 0) \
+                                 : __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[(I0) + i][j], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0)
+#define ANIP_G2_DMA_B(I)                                  \
+    if (CONV) fire_b(nst, I);                             \
+    else issue_b1(kt_begin + t + 1, nst, I)
+#define ANIP_G2_DMA_A(I)                                  \
+    if (CONV) fire_a(nst, I);                             \
+    else issue_a1(kt_begin + t + 1, nst, I)
+    // SCHED == 2 (-DANIP_GEMM2_TIMING builds only): the same loop with s_memtime stamps around every segment and barrier;
+    // waves 0 and 4 of the middle block write, per sub-step j, the summed cycles of [LOAD work, wait at the barrier
+    // closing LOAD, COMPUTE work, wait at the barrier closing COMPUTE] to p.workspace (tools/exp_gemm_timing.py)
+    constexpr bool TIMED = (SCHED == 2);
+    uint32_t tacc[20];      // [4j + {LOAD, barrier, COMPUTE, barrier}], [16 + j]: LOAD up to lgkmcnt(0), the rest of LOAD = DMA wait
+    uint64_t tprev = 0;
+    if (TIMED) {
+#pragma unroll
+      for (int q = 0; q < 20; ++q) tacc[q] = 0;
+      tprev = __builtin_readcyclecounter();
+    }
+#define ANIP_G2_STAMP(Q)                                    \
+    if (TIMED) {                                            \
+      const uint64_t now_ = __builtin_readcyclecounter();   \
+      tacc[Q] += (uint32_t)(now_ - tprev);                  \
+      tprev = now_;                                         \
+    }
     for (int t = 0; t < nk; ++t) {
       const char* sa = smem + (t & 1) * STAGE;
       const char* sb = sa + A_BYTES;
       const int nst = (t + 1) & 1;
       const bool more = t + 1 < nk;                 // block-uniform
-      const int ktn = kt_begin + t + 1;
-      // ---- j = 0: A-lo x B(k-half 0); stage the first half of B of tile t+1
+      // ---- j = 0: A-lo x B(k-half 0); stage B blocks 0, 1 of tile t+1; A-hi of THIS tile must have landed
 #pragma unroll
-      for (int j = 0; j < NB; ++j) bf0[j] = *(const f16x8*)(sb + (tile_c(j) + fr) * RB + koff[0]);
+      for (int j = 0; j < NB; ++j) bf[j] = *(const f16x8*)(sb + (tile_c(j) + fr) * RB + koff[0]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) af[i] = *(const f16x8*)(sa + a_lo + i * 16 * RB + koff[0]);
       if (more) {
-#pragma unroll
-        for (int i = 0; i < NB_I; ++i)
-          if (b_first(i)) issue_b1(ktn, nst, i);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      ANIP_G2_BAR();
-      ANIP_G2_MMA(0, bf0);
-      ANIP_G2_BAR();
-      // ---- j = 1: A-lo x B(k-half 1); stage the second half of B; A-hi of THIS tile must have landed
-#pragma unroll
-      for (int j = 0; j < NB; ++j) bf1[j] = *(const f16x8*)(sb + (tile_c(j) + fr) * RB + koff[1]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *(const f16x8*)(sa + a_lo + i * 16 * RB + koff[1]);
-      if (more) {
-#pragma unroll
-        for (int i = 0; i < NB_I; ++i)
-          if (!b_first(i)) issue_b1(ktn, nst, i);
-        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NB_I) : "memory");   // every wave stages NB_I B blocks per tile
+        ANIP_G2_DMA_B(0);
+        ANIP_G2_DMA_B(1);
+        if (TIMED) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ANIP_G2_STAMP(16); }
+        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");   // leaves the 2 B blocks just issued: A-hi(t) landed
       } else {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       }
+      ANIP_G2_STAMP(0);
       ANIP_G2_BAR();
-      ANIP_G2_MMA(0, bf1);
+      ANIP_G2_STAMP(1);
+      ANIP_G2_MMA(0);
+      ANIP_G2_STAMP(2);
       ANIP_G2_BAR();
-      // ---- j = 2: A-hi x B(k-half 1); stage A-lo of tile t+1
-#pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *(const f16x8*)(sa + a_hi + i * 16 * RB + koff[1]);
-      if (more) {
-        issue_a1(ktn, nst, 0);
-        issue_a1(ktn, nst, 1);
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      ANIP_G2_BAR();
-      ANIP_G2_MMA(4, bf1);
-      ANIP_G2_BAR();
-      // ---- j = 3: A-hi x B(k-half 0); stage A-hi of tile t+1; everything of tile t+1 but that must have landed
+      ANIP_G2_STAMP(3);
+      // ---- j = 1: A-hi x B(k-half 0); stage the remaining B blocks
 #pragma unroll
       for (int i = 0; i < 4; ++i) af[i] = *(const f16x8*)(sa + a_hi + i * 16 * RB + koff[0]);
       if (more) {
-        issue_a1(ktn, nst, 2);
-        issue_a1(ktn, nst, 3);
+#pragma unroll
+        for (int i = 2; i < NB_I; ++i) { ANIP_G2_DMA_B(i); }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      ANIP_G2_STAMP(4);
+      ANIP_G2_BAR();
+      ANIP_G2_STAMP(5);
+      ANIP_G2_MMA(4);
+      ANIP_G2_STAMP(6);
+      ANIP_G2_BAR();
+      ANIP_G2_STAMP(7);
+      // ---- j = 2: A-hi x B(k-half 1) (the B fragments are replaced: one set of B registers); stage A-lo of tile t+1
+#pragma unroll
+      for (int j = 0; j < NB; ++j) bf[j] = *(const f16x8*)(sb + (tile_c(j) + fr) * RB + koff[1]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *(const f16x8*)(sa + a_hi + i * 16 * RB + koff[1]);
+      if (more) {
+        ANIP_G2_DMA_A(0);
+        ANIP_G2_DMA_A(1);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      ANIP_G2_STAMP(8);
+      ANIP_G2_BAR();
+      ANIP_G2_STAMP(9);
+      ANIP_G2_MMA(4);
+      ANIP_G2_STAMP(10);
+      ANIP_G2_BAR();
+      ANIP_G2_STAMP(11);
+      // ---- j = 3: A-lo x B(k-half 1); stage A-hi of tile t+1; everything of tile t+1 but that must have landed
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = *(const f16x8*)(sa + a_lo + i * 16 * RB + koff[1]);
+      if (more) {
+        ANIP_G2_DMA_A(2);
+        ANIP_G2_DMA_A(3);
+        if (TIMED) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ANIP_G2_STAMP(19); }
         asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
       } else {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       }
+      ANIP_G2_STAMP(12);
       ANIP_G2_BAR();
-      ANIP_G2_MMA(4, bf0);
+      ANIP_G2_STAMP(13);
+      ANIP_G2_MMA(0);
+      // conv: the scalar operands of tile t+2 (its first part is fired in the next load segment) behind these MFMAs.
+      // (The plain GEMM issues with its per-instruction arithmetic in place: hoisting it measured 4-6 % SLOWER —
+      // the main loop waits for DMA data, not for instruction issue; profiles/r03/e_kbench_prepared_operands.jsonl.)
+      if (CONV && t + 2 < nk) prepare(kt_begin + t + 2);
+      ANIP_G2_STAMP(14);
       ANIP_G2_BAR();
+      ANIP_G2_STAMP(15);
     }
     if (grp == 0) __builtin_amdgcn_s_barrier();
+    if (TIMED && p.workspace != nullptr && blockIdx.x == gridDim.x / 2 && (wave & 3) == 0 && lane == 0) {
+      uint32_t* o = (uint32_t*)p.workspace + grp * 32;
+#pragma unroll
+      for (int q = 0; q < 20; ++q) o[q] = tacc[q];
+      o[20] = (uint32_t)nk;
+    }
+#undef ANIP_G2_STAMP
+#undef ANIP_G2_DMA_A
+#undef ANIP_G2_DMA_B
 #undef ANIP_G2_BAR
 #undef ANIP_G2_MMA
   } else if (PHASED) {
@@ -878,6 +1021,12 @@ static int gemm2_sched() {
 template <int BM2, int BN, int NW, int WNW, int BKT, int NST>
 int dispatch_gemm2(const anip_gemm_params& p, hipStream_t stream, int splitk = 1) {
   if constexpr (NST == 2 && BKT == 64 && NW == 8) {
+#ifdef ANIP_GEMM2_TIMING
+    if (gemm2_sched() == 2) {
+      if (p.conv) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, true, false, 2>(p, stream, splitk);
+      return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, false, 2>(p, stream, splitk);
+    }
+#endif
     if (gemm2_sched() == 1) {
       if (p.conv) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, true, false, 1>(p, stream, splitk);
       if (p.trans_out) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, true, 1>(p, stream, splitk);

@@ -275,7 +275,7 @@ def layernorm(x, gamma, beta, eps=1e-5, pe=None, rows_per_frame=0, frames=0):
 
 
 def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None, act=0, out_f32=False,
-         alpha=1.0, out=None, conv=None, batch=1, ldo=None, ldr=None, trans_out=False, head_dim=0):
+         alpha=1.0, out=None, conv=None, batch=1, ldo=None, ldr=None, trans_out=False, head_dim=0, debug_ws=None):
     """out = epilogue(alpha * A @ W^T).
 
     A (M, K) fp16 [+ A2 (M, K2): K split over two sources]; W (N, K) fp16; bias (N,) fp32;
@@ -376,6 +376,8 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
         if wsb > 0:
             ws = torch.empty((wsb,), dtype=torch.uint8, device=A.device)
             p.workspace, p.workspace_bytes = _p(ws), wsb
+    if debug_ws is not None:     # experiment builds only (segment-timing kernels write their counters here)
+        p.workspace, p.workspace_bytes = _p(debug_ws), debug_ws.numel() * debug_ws.element_size()
     L.check(lib.anip_gemm(C.byref(p), _stream()), "anip_gemm")
     return out
 
@@ -398,7 +400,7 @@ def ffn_geglu(x, w1p, b1p, w2, b2, residual=None):
 
 
 def conv3x3(x, Wp, bias, stride=1, pad=1, upsample=False, pad_hi=None, rowbias=None, rows_per_group=0,
-            residual=None, out_f32=False, korder=None):
+            residual=None, out_f32=False, korder=None, debug_ws=None):
     """x (N, H, W, Cin) fp16, Wp (Cout, 9*Cin) packed by pack_conv3x3 -> (N, Ho, Wo, Cout).
     pad = low-side padding; pad_hi (default = pad) = high-side padding (VAE encoder uses 0/1).
     korder: the K order Wp was packed in (default: pack_conv3x3's default for this Cin)."""
@@ -412,7 +414,7 @@ def conv3x3(x, Wp, bias, stride=1, pad=1, upsample=False, pad_hi=None, rowbias=N
                 korder=conv_korder(Cin) if korder is None else korder)
     res2 = residual.reshape(-1, Wp.shape[0]) if residual is not None else None
     out = gemm(x, Wp, bias, rowbias=rowbias, rows_per_group=rows_per_group, residual=res2, conv=conv,
-               out_f32=out_f32)
+               out_f32=out_f32, debug_ws=debug_ws)
     return out.reshape(N, Ho, Wo, Wp.shape[0])
 
 

@@ -44,6 +44,32 @@ PY
     N=${STEP#ktests:}
     timeout 900 python -m pytest tests/test_hip_ops.py -m gpu -q -k "gemm or conv3x3 or ffn" > $OUT/ktests_$N.log 2>&1; echo "rc=$?" >> $OUT/ktests_$N.log
     grep -E "^FAILED|^ERROR|passed|failed|rc=" $OUT/ktests_$N.log | tail -n 25 ;;
+  pmclist)
+    rocprofv3 -L > $OUT/rocprofv3_counters.txt 2>&1; grep -c . $OUT/rocprofv3_counters.txt ;;
+  pmck:*)     # pmck:<name>:<what>  — SQ / TCC counter passes over tools/pmc_kernels.py <what> under the current environment
+    AB=${STEP#pmck:}; N=${AB%%:*}; W=${AB##*:}
+    i=0
+    for CTRS in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" "SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE"; do
+      i=$((i+1))
+      ( cd /tmp && timeout 300 rocprofv3 --pmc $CTRS --kernel-trace -f csv -d $OUT/pmck_$N/pass$i -o p -- python $GRAFT_REPO_ROOT/tools/pmc_kernels.py $W > $OUT/pmck_${N}_pass$i.log 2>&1; echo "pmck $N pass $i rc=$?" )
+    done
+    find $OUT/pmck_$N -name "*kernel_trace*" -delete 2>/dev/null
+    python tools/pmc_summarize.py $OUT/pmck_$N $OUT/pmck_${N}_summary.json 2>&1 | tail -n 1
+    python - <<PY
+import json
+d=json.load(open("$OUT/pmck_${N}_summary.json"))
+for r in d["kernels"]:
+    m=r["mean"]
+    if "gemm2" not in r["kernel"] and "attn" not in r["kernel"]: continue
+    g=m.get("GRBM_GUI_ACTIVE",0)/8
+    wc=max(1,m.get("SQ_WAVE_CYCLES",1))
+    hit,miss=m.get("TCC_HIT_sum",0),m.get("TCC_MISS_sum",0)
+    print("%-60s grid=%-8s n=%d cyc=%8.0f mfma=%.2f wait_any=%.2f wait_inst=%.2f active=%.2f | L2 hit=%.3f req=%.2e | rd=%6.0fMB wr=%6.0fMB | lds_conf/idx=%.3f"%(
+        r["kernel"][:60], r["grid"], r["launches"], g, r.get("mfma_busy_frac",-1), m.get("SQ_WAIT_ANY",0)/wc, m.get("SQ_WAIT_INST_ANY",0)/wc, m.get("SQ_ACTIVE_INST_ANY",0)/wc,
+        hit/max(1,hit+miss), m.get("TCC_REQ_sum",0), r.get("hbm_read_bytes_per_launch",0)/1e6, r.get("hbm_write_bytes_per_launch",0)/1e6,
+        m.get("SQ_LDS_BANK_CONFLICT",0)/max(1,m.get("SQ_LDS_IDX_ACTIVE",1))))
+PY
+    ;;
   vaebatch)
     timeout 600 python tests/bisect_parity.py --net vaebatch --sizes 32 64 96 --frames 16 --backends hip --out $OUT/vae_batch_vs_single.json > $OUT/vae_batch_vs_single.log 2>&1; echo "rc=$?" >> $OUT/vae_batch_vs_single.log
     grep -E "VAE batch|rc=|Error" $OUT/vae_batch_vs_single.log | tail -n 8
