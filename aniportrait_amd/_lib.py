@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # ANIP_LIB: an experiment build of the same ABI (aniportrait_amd/build.py --out=...); the product is the default path
 LIB_PATH = os.environ.get("ANIP_LIB") or os.path.join(HERE, "lib", "libaniportrait_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -47,6 +47,8 @@ SIGNATURES = {
     "anip_groupnorm_single_launch": (c_int, [c_int, c_int64, c_int, c_int]),
     "anip_groupnorm": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64,
                                c_int, c_float, c_int, c_void_p, c_void_p]),
+    "anip_groupnorm_frames": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int64,
+                                      c_int, c_float, c_int, c_int, c_void_p, c_void_p]),
     "anip_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_int64,
                                c_int, c_void_p]),
     "anip_gemm_workspace_bytes": (c_int64, [C.POINTER(GemmParams)]),

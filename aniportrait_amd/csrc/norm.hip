@@ -87,7 +87,7 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const f16* __restrict__ x1
                                                      int C2, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, f16* __restrict__ y, int64_t HW,
                                                      int G, float eps, int silu, const float* __restrict__ ws,
-                                                     int nchunks, int64_t ppc_apply) {
+                                                     int nchunks, int64_t ppc_apply, int fps) {
   extern __shared__ __attribute__((aligned(16))) float sm[];  // scale[C], shift[C], then mean[G], rstd[G]
   const int C = C1 + C2;
   const int CV = C >> 3;
@@ -99,13 +99,18 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const f16* __restrict__ x1
   float* grstd = gmean + G;
   const int cpg = C / G;
   if (tid < G) {
+    // fps = frames per statistic: 1 = per-frame GroupNorm (InflatedGroupNorm); f = plain nn.GroupNorm on the 5-D tensor
+    // (src/models/resnet.py:161-164 with use_inflated_groupnorm=False, configs/inference/inference_v1.yaml): the
+    // statistics run over (C/G, f, H, W) of a sample — the per-(frame, chunk) partial sums of its f frames are added here
     float S = 0.f, Q = 0.f;
-    for (int ch = 0; ch < nchunks; ++ch) {
-      const float* o = ws + (((int64_t)n * nchunks + ch) * G + tid) * 2;
-      S += o[0];
-      Q += o[1];
-    }
-    const float cnt = (float)((double)HW * cpg);
+    const int n_first = (n / fps) * fps;
+    for (int fr = 0; fr < fps; ++fr)
+      for (int ch = 0; ch < nchunks; ++ch) {
+        const float* o = ws + (((int64_t)(n_first + fr) * nchunks + ch) * G + tid) * 2;
+        S += o[0];
+        Q += o[1];
+      }
+    const float cnt = (float)((double)HW * cpg * fps);
     const float mean = S / cnt;
     const float var = fmaxf(Q / cnt - mean * mean, 0.f);
     gmean[tid] = mean;
@@ -385,14 +390,22 @@ extern "C" int anip_groupnorm_single_launch(int N, int64_t HW, int C, int G) {
 
 extern "C" int anip_groupnorm(const void* x1, int C1, const void* x2, int C2, const float* gamma, const float* beta,
                               void* y, int N, int64_t HW, int G, float eps, int silu, float* ws, void* stream) {
+  return anip_groupnorm_frames(x1, C1, x2, C2, gamma, beta, y, N, HW, G, eps, silu, 1, ws, stream);
+}
+
+extern "C" int anip_groupnorm_frames(const void* x1, int C1, const void* x2, int C2, const float* gamma, const float* beta,
+                                     void* y, int N, int64_t HW, int G, float eps, int silu, int frames_per_stat, float* ws,
+                                     void* stream) {
   const int C = C1 + C2;
+  ANIP_REQUIRE(frames_per_stat >= 1 && N % frames_per_stat == 0,
+               "anip_groupnorm_frames: N=%d is not a multiple of frames_per_stat=%d", N, frames_per_stat);
   ANIP_REQUIRE(x1 && y && gamma && beta && ws, "anip_groupnorm: null pointer");
   ANIP_REQUIRE(N > 0 && HW > 0 && G > 0 && G <= NT, "anip_groupnorm: bad sizes N=%d HW=%lld G=%d", N, (long long)HW, G);
   ANIP_REQUIRE((C1 & 7) == 0 && (C2 & 7) == 0 && C % G == 0, "anip_groupnorm: C1=%d C2=%d must be multiples of 8, C %% G == 0", C1, C2);
   ANIP_REQUIRE((C2 == 0) == (x2 == nullptr), "anip_groupnorm: x2/C2 mismatch");
   ANIP_REQUIRE(C <= 8192, "anip_groupnorm: C=%d too large", C);
   {
-    if (anip_groupnorm_single_launch(N, HW, C, G)) {
+    if (frames_per_stat == 1 && anip_groupnorm_single_launch(N, HW, C, G)) {
       const int cpg = C / G;
       const int V = ((cpg & 7) == 0) ? 8 : ((cpg & 3) == 0) ? 4 : 2;
       AnipProfScope prof_(ANIP_K_GN_APPLY, (void*)stream);
@@ -435,7 +448,8 @@ extern "C" int anip_groupnorm(const void* x1, int C1, const void* x2, int C2, co
   {
     AnipProfScope prof_(ANIP_K_GN_APPLY, (void*)stream);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(achunks, N), dim3(NT), sm2, (hipStream_t)stream, (const f16*)x1, C1,
-                       (const f16*)x2, C2, gamma, beta, (f16*)y, HW, G, eps, silu, (const float*)ws, nchunks, ppa);
+                       (const f16*)x2, C2, gamma, beta, (f16*)y, HW, G, eps, silu, (const float*)ws, nchunks, ppa,
+                       frames_per_stat);
   }
   ANIP_LAUNCH_CHECK("anip_groupnorm(apply)");
   return 0;

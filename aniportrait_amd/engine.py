@@ -162,20 +162,22 @@ class PackedNet:
 # blocks
 # ----------------------------------------------------------------------------------------------------
 
-def resnet(net, p, x, skip, temb_rb, rows_per_group, eps, groups=32):
+def resnet(net, p, x, skip, temb_rb, rows_per_group, eps, groups=32, gn_frames=1):
     """ResnetBlock3D / ResnetBlock2D (src/models/resnet.py:218-248) on x (N,H,W,C1) [+ skip (N,H,W,C2),
-    the torch.cat of src/models/unet_3d_blocks.py:697,826 fused into norm1 and the shortcut GEMM]."""
+    the torch.cat of src/models/unet_3d_blocks.py:697,826 fused into norm1 and the shortcut GEMM].
+    gn_frames: frames per GroupNorm statistic (1: InflatedGroupNorm, per frame; f: nn.GroupNorm over the 5-D tensor —
+    use_inflated_groupnorm=False, src/models/resnet.py:161-164)."""
     N, H, W, C1 = x.shape
     HW = H * W
     x2 = None if skip is None else skip.reshape(N, HW, -1)
     h = ops.groupnorm(x.reshape(N, HW, C1), net.f32(p + ".norm1.weight"), net.f32(p + ".norm1.bias"), groups, eps,
-                      True, x2=x2)
+                      True, x2=x2, frames_per_stat=gn_frames)
     Cin = h.shape[-1]
     h = ops.conv3x3(h.reshape(N, H, W, Cin), net.conv3(p + ".conv1.weight"), net.f32(p + ".conv1.bias"),
                     rowbias=temb_rb, rows_per_group=rows_per_group)
     Co = h.shape[-1]
     h = ops.groupnorm(h.reshape(N, HW, Co), net.f32(p + ".norm2.weight"), net.f32(p + ".norm2.bias"), groups, eps,
-                      True)
+                      True, frames_per_stat=gn_frames)
     if net.has(p + ".conv_shortcut.weight"):
         sc = ops.gemm(x.reshape(N * HW, C1), net.lin(p + ".conv_shortcut.weight"), net.f32(p + ".conv_shortcut.bias"),
                       A2=None if skip is None else skip.reshape(N * HW, -1))
@@ -429,6 +431,10 @@ def unet_forward(net, cfg, x, b, f, t, ehs, attn2_cache, refs, with_motion, ref_
     groups = cfg["norm_num_groups"]
     N, H, W, _ = x.shape
     assert N == b * f
+    # ResnetBlock3D norms and conv_norm_out: per frame (InflatedGroupNorm) or over the sample's f frames (nn.GroupNorm on
+    # (b, c, f, h, w): use_inflated_groupnorm=False, configs/inference/inference_v1.yaml); the Transformer3D / motion-module
+    # norms see (b f) c h w in both variants (src/models/transformer_3d.py:115-124, src/models/motion_module.py:151-156)
+    gn_frames = 1 if (not with_motion or cfg.get("use_inflated_groupnorm", True)) else f
 
     # temb_in: the sinusoid already on the device (fp32 (b, C0)) — lets a captured hipGraph of this forward be
     # replayed for every DDIM step by rewriting that one buffer
@@ -451,7 +457,7 @@ def unet_forward(net, cfg, x, b, f, t, ehs, attn2_cache, refs, with_motion, ref_
     def res(p, x, skip=None):
         o, c = toffs[p + ".time_emb_proj"]
         hw = x.shape[1] * x.shape[2]
-        return see(p, resnet(net, p, x, skip, temb_all[:, o:o + c], f * hw, eps, groups))
+        return see(p, resnet(net, p, x, skip, temb_all[:, o:o + c], f * hw, eps, groups, gn_frames))
 
     def attn(p, x):
         return see(p, spatial_transformer(net, p, x, heads, a2[p], f, refs.get(p), ref_index,
@@ -502,7 +508,7 @@ def unet_forward(net, cfg, x, b, f, t, ehs, attn2_cache, refs, with_motion, ref_
         return x
     C = x.shape[-1]
     h = ops.groupnorm(x.reshape(N, H * W, C), net.f32("conv_norm_out.weight"), net.f32("conv_norm_out.bias"), groups,
-                      eps, True)
+                      eps, True, frames_per_stat=gn_frames)
     return see("conv_out", ops.conv3x3(h.reshape(N, H, W, C), net.conv3("conv_out.weight"), net.f32("conv_out.bias")))
 
 

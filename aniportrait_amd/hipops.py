@@ -239,8 +239,9 @@ def pack_geglu(w, b):
 # ops
 # ------------------------------------------------------------------------------------------------
 
-def groupnorm(x1, gamma, beta, groups, eps, silu, x2=None):
-    """x1 (N, HW, C1) [, x2 (N, HW, C2)] -> (N, HW, C1+C2): GroupNorm(+SiLU) of the channel concat."""
+def groupnorm(x1, gamma, beta, groups, eps, silu, x2=None, frames_per_stat=1):
+    """x1 (N, HW, C1) [, x2 (N, HW, C2)] -> (N, HW, C1+C2): GroupNorm(+SiLU) of the channel concat.
+    frames_per_stat = f: statistics over f consecutive images (nn.GroupNorm on the 5-D tensor, inference_v1.yaml)."""
     lib = L.load()
     _req(x1, F16, "x1")
     N, HW, C1 = x1.shape
@@ -252,14 +253,14 @@ def groupnorm(x1, gamma, beta, groups, eps, silu, x2=None):
     y = torch.empty((N, HW, Ctot), dtype=F16, device=x1.device)
     ws = torch.empty((lib.anip_groupnorm_ws_floats(N, HW, Ctot, groups),), dtype=F32, device=x1.device)
     if _WORK is not None:
-        if lib.anip_groupnorm_single_launch(N, HW, Ctot, groups):
+        if frames_per_stat == 1 and lib.anip_groupnorm_single_launch(N, HW, Ctot, groups):
             _work(K_GN_APPLY, N * HW * Ctot * 4, f"N{N} HW{HW} C{Ctot} silu{int(bool(silu))} slab")
         else:
             _work(K_GN_STATS, N * HW * Ctot * 2, f"N{N} HW{HW} C{Ctot}")
             _work(K_GN_APPLY, N * HW * Ctot * 4, f"N{N} HW{HW} C{Ctot} silu{int(bool(silu))}")
-    L.check(lib.anip_groupnorm(_p(x1), C1, _p(x2), C2, _p(_req(gamma, F32, "gamma")), _p(_req(beta, F32, "beta")),
-                               _p(y), N, HW, groups, float(eps), int(bool(silu)), _p(ws), _stream()),
-            "anip_groupnorm")
+    L.check(lib.anip_groupnorm_frames(_p(x1), C1, _p(x2), C2, _p(_req(gamma, F32, "gamma")), _p(_req(beta, F32, "beta")),
+                                      _p(y), N, HW, groups, float(eps), int(bool(silu)), int(frames_per_stat), _p(ws),
+                                      _stream()), "anip_groupnorm_frames")
     return y
 
 

@@ -158,9 +158,6 @@ class UNet3DConditionModel(_UNetBase):
     @staticmethod
     def _check_config(cfg):
         _UNetBase._check_config(cfg)
-        if not cfg["use_inflated_groupnorm"]:
-            raise NotImplementedError("use_inflated_groupnorm=False (inference_v1.yaml: GroupNorm statistics across "
-                                      "frames) is outside the built path; inference_v2.yaml sets it True")
         if cfg["unet_use_cross_frame_attention"] or cfg["unet_use_temporal_attention"]:
             raise NotImplementedError("unet_use_cross_frame_attention / unet_use_temporal_attention")
         if cfg["use_motion_module"]:

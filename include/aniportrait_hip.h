@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ANIP_ABI_VERSION 10
+#define ANIP_ABI_VERSION 11
 
 int anip_version(void);
 const char* anip_last_error(void);
@@ -45,6 +45,13 @@ int64_t anip_groupnorm_ws_floats(int N, int64_t HW, int C, int G);
 int anip_groupnorm_single_launch(int N, int64_t HW, int C, int G);
 int anip_groupnorm(const void* x1, int C1, const void* x2, int C2, const float* gamma, const float* beta,
                    void* y, int N, int64_t HW, int G, float eps, int silu, float* ws, void* stream);
+/* the same with statistics over `frames_per_stat` consecutive images (N % frames_per_stat == 0): plain nn.GroupNorm on the
+ * (b, c, f, h, w) tensor — ResnetBlock3D norm1 / norm2 and conv_norm_out when use_inflated_groupnorm is False
+ * (src/models/resnet.py:161-164,186-193, src/models/unet_3d.py:237-246; configs/inference/inference_v1.yaml).
+ * frames_per_stat = 1 is anip_groupnorm. */
+int anip_groupnorm_frames(const void* x1, int C1, const void* x2, int C2, const float* gamma, const float* beta,
+                          void* y, int N, int64_t HW, int G, float eps, int silu, int frames_per_stat, float* ws,
+                          void* stream);
 
 /* ---- LayerNorm over the last dim --------------------------------------------------------------
  * replaces nn.LayerNorm: src/models/attention.py:331-335,352-362, src/models/motion_module.py:228,234.

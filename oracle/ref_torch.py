@@ -93,17 +93,31 @@ def feed_forward(sd, p, x):
     return _lin(sd, p + ".net.2", h * F.gelu(g))
 
 
-def resnet_block(sd, p, x, temb, eps, groups=32):
+def _gn_frames(sd, p, x, eps, groups, f):
+    """nn.GroupNorm on the (b, c, f, h, w) tensor (resnet.py:161-164,186-193 with use_inflated_groupnorm=False,
+    inference_v1.yaml): x (b*f, C, H, W), statistics over (C/G, f, H, W) per sample; f = 1 is the per-frame norm."""
+    if f == 1:
+        return _gn(sd, p, x, eps, groups)
+    N, C, H, W = x.shape
+    x5 = x.reshape(N // f, f, C, H, W).permute(0, 2, 1, 3, 4)
+    y5 = F.group_norm(x5, groups, sd[p + ".weight"], sd[p + ".bias"], eps)
+    return y5.permute(0, 2, 1, 3, 4).reshape(N, C, H, W)
+
+
+def resnet_block(sd, p, x, temb, eps, groups=32, gn_frames=1):
     """resnet.py:218-248 (f folded into the batch) == diffusers ResnetBlock2D."""
-    h = F.silu(_gn(sd, p + ".norm1", x, eps, groups))
+    h = F.silu(_gn_frames(sd, p + ".norm1", x, eps, groups, gn_frames))
     h = _conv(sd, p + ".conv1", h)
     if temb is not None and (p + ".time_emb_proj.weight") in sd:
         h = h + _lin(sd, p + ".time_emb_proj", F.silu(temb))[:, :, None, None]
-    h = F.silu(_gn(sd, p + ".norm2", h, eps, groups))
+    h = F.silu(_gn_frames(sd, p + ".norm2", h, eps, groups, gn_frames))
     h = _conv(sd, p + ".conv2", h)
     if (p + ".conv_shortcut.weight") in sd:
         x = _conv(sd, p + ".conv_shortcut", x, padding=0)
     return x + h
+
+
+_resnet_block_impl = resnet_block
 
 
 # ----------------------------------------------------------------------------------------------
@@ -217,6 +231,10 @@ def _unet_body(sd, cfg, x, emb, ehs_rows, f, mode, banks, n_uncond, pose_fea, wi
     nblk = len(cfg["block_out_channels"])
     lpb = cfg["layers_per_block"]
     b = x.shape[0] // f
+    gnf = 1 if (not with_motion or cfg.get("use_inflated_groupnorm", True)) else f   # frames per ResnetBlock3D GN statistic
+
+    def resnet_block(sd_, p_, x_, temb_, eps_):   # every resnet of this walk shares gn_frames
+        return _resnet_block_impl(sd_, p_, x_, temb_, eps_, gn_frames=gnf)
 
     def attn(path, x):
         kw = dict(mode=mode)
@@ -284,7 +302,7 @@ def unet3d_forward(sd, cfg, sample, t, ehs, pose_fea=None, banks=None, do_cfg=Tr
     mode = "read" if banks is not None else "plain"
     n_uncond = (b * f) // 2 if (do_cfg and banks is not None) else 0
     x = _unet_body(sd, cfg, x, emb, ehs_rows, f, mode, banks, n_uncond, pose_fea, True, tap)
-    x = F.silu(_gn(sd, "conv_norm_out", x, cfg["norm_eps"]))
+    x = F.silu(_gn_frames(sd, "conv_norm_out", x, cfg["norm_eps"], 32, 1 if cfg.get("use_inflated_groupnorm", True) else f))
     x = _conv(sd, "conv_out", x)
     if tap is not None:
         x = tap("conv_out", x)

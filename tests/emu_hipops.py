@@ -14,10 +14,12 @@ import torch.nn.functional as F
 F16, F32 = torch.float16, torch.float32
 
 
-def groupnorm(x1, gamma, beta, groups, eps, silu, x2=None):
+def groupnorm(x1, gamma, beta, groups, eps, silu, x2=None, frames_per_stat=1):
     x = x1 if x2 is None else torch.cat([x1, x2], dim=-1)
     N, HW, C = x.shape
-    y = F.group_norm(x.float().permute(0, 2, 1), groups, gamma.float(), beta.float(), eps).permute(0, 2, 1)
+    f = int(frames_per_stat)
+    xs = x.float().reshape(N // f, f * HW, C)          # statistics over f consecutive images
+    y = F.group_norm(xs.permute(0, 2, 1), groups, gamma.float(), beta.float(), eps).permute(0, 2, 1).reshape(N, HW, C)
     if silu:
         y = F.silu(y)
     return y.to(F16).contiguous()

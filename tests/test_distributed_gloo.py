@@ -203,7 +203,9 @@ def _eight_rank_worker(rank, world, port, q):
         import emu_hipops
         emu_hipops.install(_Patch())
         out = _run_long_clip(dist.group.WORLD)
-        q.put((rank, None if out is None else out.videos))
+        # by value (numpy): a torch tensor travels through the queue as a shared-memory handle served by THIS process,
+        # which may have exited before the parent reads it
+        q.put((rank, None if out is None else out.videos.numpy()))
     finally:
         dist.destroy_process_group()
 
@@ -231,7 +233,7 @@ def test_eight_rank_long_clip_equals_single_process_bit_for_bit(monkeypatch):
         p.join(120)
         assert p.exitcode == 0
     assert all(res[r] is None for r in range(1, world))
-    got = res[0]
+    got = torch.from_numpy(res[0])
     assert tuple(got.shape) == tuple(ref.shape) == (1, 3, 78, 64, 64)
     assert torch.isfinite(got).all() and float(got.std()) > 1e-3
     assert torch.equal(got, ref), f"8-rank video differs from world size 1: max |d| = {float((got - ref).abs().max()):.3e}"

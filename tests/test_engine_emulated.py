@@ -92,3 +92,29 @@ def test_pipeline_host_logic_matches_reference_video(emu, case):
         want = (vid[0].permute(1, 2, 3, 0) * 255).numpy().astype("uint8")       # (L, H, W, 3)
         assert u8.dtype == torch.uint8 and tuple(u8.shape) == (i["L"], i["H"], i["W"], 3)
         assert (u8.numpy() == want).all()
+
+
+@torch.no_grad()
+def test_inference_v1_groupnorm_variant_engine_matches_reference(emu):
+    """use_inflated_groupnorm=False (configs/inference/inference_v1.yaml): GroupNorm statistics over the sample's frames in
+    the ResnetBlock3D norms and conv_norm_out — the engine's `frames_per_stat` path against the reference-made golden"""
+    import copy
+
+    from aniportrait_amd import configs as C
+    from aniportrait_amd.unet import UNet3DConditionModel
+    from golden_inputs import unet_case
+    from util import oracle_state_dicts
+    kw = copy.deepcopy(C.unet3d_kwargs(True))
+    kw.update(use_inflated_groupnorm=False, motion_module_mid_block=False)
+    kw["motion_module_kwargs"]["temporal_position_encoding_max_len"] = 24
+    net = UNet3DConditionModel(**kw)
+    sd = oracle_state_dicts(True, keys=["denoising_unet"])["denoising_unet"]
+    missing, unexpected = net.load_state_dict({k: v for k, v in sd.items() if not k.startswith("mid_block.motion_modules")},
+                                              strict=False)
+    assert not unexpected and all(m.endswith(".pe") for m in missing), (missing[:3], unexpected[:3])
+    net = net.to("cpu", torch.float16)
+    c = unet_case(True)
+    out = net(c["lat"], torch.tensor(c["t"]), encoder_hidden_states=c["ehs"], pose_cond_fea=None)
+    gold = load_golden("small_models_v1.pt")
+    assert rel_err(out.sample, gold["unet_out_v1"]) < TOL
+    assert rel_err(out.sample, gold["unet_out_v1_if_inflated"]) > 1e-2

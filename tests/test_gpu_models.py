@@ -263,3 +263,31 @@ def test_full_size_properties_768():
     rd.clear()
     img = vae.decode(torch.randn((1, 4, h, h), generator=g, device=DEV).half()).sample
     assert img.shape == (1, 3, 8 * h, 8 * h) and torch.isfinite(img).all()
+
+
+@torch.no_grad()
+def test_inference_v1_groupnorm_variant_on_the_gpu():
+    """configs/inference/inference_v1.yaml's UNet3D (use_inflated_groupnorm=False: GroupNorm statistics across the sample's
+    frames in the ResnetBlock3D norms and conv_norm_out; no mid-block motion module) on the HIP kernels against the golden
+    made by the reference's own class"""
+    import copy
+
+    from aniportrait_amd import configs as C
+    from aniportrait_amd.unet import UNet3DConditionModel
+    from golden_inputs import unet_case
+    from util import load_golden, oracle_state_dicts, rel_err
+    kw = copy.deepcopy(C.unet3d_kwargs(True))
+    kw.update(use_inflated_groupnorm=False, motion_module_mid_block=False)
+    kw["motion_module_kwargs"]["temporal_position_encoding_max_len"] = 24
+    net = UNet3DConditionModel(**kw)
+    sd = oracle_state_dicts(True, keys=["denoising_unet"])["denoising_unet"]
+    missing, unexpected = net.load_state_dict({k: v for k, v in sd.items() if not k.startswith("mid_block.motion_modules")},
+                                              strict=False)
+    assert not unexpected and all(m.endswith(".pe") for m in missing)
+    net = net.to("cuda", torch.float16)
+    c = unet_case(True)
+    out = net(c["lat"].cuda(), torch.tensor(c["t"]), encoder_hidden_states=c["ehs"].cuda(), pose_cond_fea=None).sample
+    gold = load_golden("small_models_v1.pt")
+    e = rel_err(out.float().cpu(), gold["unet_out_v1"])
+    print(f"inference_v1 UNet3D (cross-frame GroupNorm) vs reference golden: {e:.2e} of max")
+    assert e < 6e-3 and rel_err(out.float().cpu(), gold["unet_out_v1_if_inflated"]) > 1e-2

@@ -209,6 +209,22 @@ def test_groupnorm(N, HW, C1, C2, silu, eps, shift):
     close(out, ref, f"groupnorm N{N} HW{HW} C{C1}+{C2}")
 
 
+@pytest.mark.parametrize("N,F_,HW,C", [(8, 4, 1024, 320), (6, 3, 4096, 640), (4, 2, 64, 1280), (16, 16, 256, 320)])
+def test_groupnorm_statistics_across_frames(N, F_, HW, C):
+    """frames_per_stat = f: nn.GroupNorm on the (b, c, f, h, w) tensor (use_inflated_groupnorm=False, inference_v1.yaml);
+    also at the 8x8 / 16x16 sizes where the per-frame norm takes the single-launch slab kernel"""
+    ops = _ops()
+    x = rnd(N, HW, C, seed=401, shift=0.3).to(DEV)
+    g = (1 + 0.1 * rnd(C, seed=402).float()).to(DEV)
+    b = (0.1 * rnd(C, seed=403).float()).to(DEV)
+    y = ops.groupnorm(x, g, b, 32, 1e-5, True, frames_per_stat=F_)
+    x5 = x.float().cpu().reshape(N // F_, F_ * HW, C).permute(0, 2, 1)
+    ref = F.silu(F.group_norm(x5, 32, g.cpu(), b.cpu(), 1e-5)).permute(0, 2, 1).reshape(N, HW, C)
+    close(y, ref, f"groupnorm over {F_} frames N={N} HW={HW} C={C}")
+    y1 = ops.groupnorm(x, g, b, 32, 1e-5, True)                  # per frame: a different result
+    assert (y1.float() - y.float()).abs().max() > 1e-2
+
+
 @pytest.mark.parametrize("M,C,pe", [(77, 320, False), (130, 1280, False), (2 * 4 * 10, 64, True), (9, 2560, False)])
 def test_layernorm(M, C, pe):
     ops = _ops()

@@ -110,3 +110,31 @@ def test_vae_real_width():
         enc = O.vae_encode_mean(sds["vae"], C.SD_VAE_FT_MSE, v["x"])
     assert rel_err(dec, gold["vae_dec"]) < TOL
     assert rel_err(enc, gold["vae_enc"]) < TOL
+
+
+def _v1_cfg():
+    import copy
+
+    from aniportrait_amd import configs as C
+    kw = copy.deepcopy(C.unet3d_kwargs(True))
+    kw.update(use_inflated_groupnorm=False, motion_module_mid_block=False)
+    kw["motion_module_kwargs"]["temporal_position_encoding_max_len"] = 24
+    return kw
+
+
+@torch.no_grad()
+def test_oracle_inference_v1_groupnorm_variant_matches_reference():
+    """configs/inference/inference_v1.yaml: use_inflated_groupnorm absent -> ResnetBlock3D norm1 / norm2 and conv_norm_out are
+    nn.GroupNorm over the 5-D tensor (statistics across the sample's frames: src/models/resnet.py:161-164,186-193,
+    src/models/unet_3d.py:237-246), no mid-block motion module — golden made by the reference's own UNet3DConditionModel"""
+    from golden_inputs import unet_case
+    from oracle import ref_torch as O
+    from util import load_golden, oracle_state_dicts, rel_err
+    gold = load_golden("small_models_v1.pt")
+    cfg = _v1_cfg()
+    sd = oracle_state_dicts(True, keys=["denoising_unet"])["denoising_unet"]
+    sd = {k: v for k, v in sd.items() if not k.startswith("mid_block.motion_modules")}
+    c = unet_case(True)
+    out = O.unet3d_forward(sd, cfg, c["lat"], c["t"], c["ehs"], None, None, True)
+    assert rel_err(out, gold["unet_out_v1"]) < 2e-4
+    assert rel_err(out, gold["unet_out_v1_if_inflated"]) > 1e-2      # the variant is live: per-frame norms differ
