@@ -384,7 +384,7 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
 
 
 def ffn_geglu(x, w1p, b1p, w2, b2, residual=None):
-    """Fused GEGLU feed-forward (anip_ffn_geglu; C = 320 only; opt-in in the engine): x (M, C) fp16, w1p / b1p packed by
+    """Fused GEGLU feed-forward (anip_ffn_geglu; C = 320 only; the engine's default there): x (M, C) fp16, w1p / b1p packed by
     pack_geglu, w2 (C, 4C) fp16, b2 (C,) fp32, residual (M, C) fp16 -> (M, C) fp16."""
     lib = L.load()
     _req(x, F16, "x")

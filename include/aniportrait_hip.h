@@ -107,7 +107,7 @@ typedef struct anip_gemm_params {
 int64_t anip_gemm_workspace_bytes(const anip_gemm_params* p);
 int anip_gemm(const anip_gemm_params* p, void* stream);
 
-/* ---- fused GEGLU feed-forward (opt-in: the engine uses it only with ANIP_FUSED_FFN=1, see csrc/ffn.hip) -----------
+/* ---- fused GEGLU feed-forward (the engine's default at C = 320; ANIP_FUSED_FFN=0 selects two anip_gemm calls) -------
  * out[M][C] = residual + b2 + W2 · ((x W1v^T + b1v) * gelu_erf(x W1g^T + b1g)):  diffusers FeedForward("geglu") of
  * src/models/attention.py:361 / src/models/motion_module.py:233 plus the block's residual add, without the M x 4C
  * intermediate ever leaving the CU.  x [M][C] fp16; w1p [8C][C] fp16 and b1p [8C] fp32 packed per 32 rows as

