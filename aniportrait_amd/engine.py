@@ -248,7 +248,7 @@ def project_reference_bank(net, p, ref, d):
     ref.stale = False
 
 
-def prepare_reference(net, cfg, refs, ehs, attn2_cache):
+def prepare_reference(net, cfg, refs, ehs, attn2_cache, attn2_slot=0):
     """Everything of a denoising forward that depends on the CLIP token and the reference banks only — the bank
     projections of the 16 hooked blocks and the collapsed attn2 vectors — refreshed in place, once per clip.  After it,
     a captured hipGraph of the forward (which reads those buffers) is valid for every DDIM step of the clip, the first
@@ -257,7 +257,7 @@ def prepare_reference(net, cfg, refs, ehs, attn2_cache):
         ref = refs.get(p)
         if ref is not None and ref.mode == "read" and ref.bank is not None and (ref.kref is None or ref.stale):
             project_reference_bank(net, p + ".transformer_blocks.0", ref, ref.bank.shape[-1] // cfg["attention_head_dim"])
-    attn2_cache.get(net, cfg, ehs, refresh=True)
+    attn2_cache.get(net, cfg, ehs, refresh=True, slot=attn2_slot)
 
 
 def transformer_block(net, p, h, Nf, T, heads, attn2_vec, rows_per_sample, ref=None, ref_index=None, stop_after_bank=False):
@@ -393,8 +393,10 @@ class Attn2Cache:
     def drop(self):
         self.pool = {}
 
-    def get(self, net, cfg, ehs, refresh=True):
-        key = (int(ehs.shape[0]), str(net.device))
+    def get(self, net, cfg, ehs, refresh=True, slot=0):
+        """slot: distinct buffer sets for same-sized embeddings that are live at the same time (the two CFG halves of a
+        step running as separate forwards on two streams)"""
+        key = (int(ehs.shape[0]), str(net.device), int(slot))
         vecs = self.pool.get(key)
         if vecs is not None and not refresh:
             return vecs
@@ -411,7 +413,7 @@ class Attn2Cache:
 
 
 def unet_forward(net, cfg, x, b, f, t, ehs, attn2_cache, refs, with_motion, ref_index=None, pose_nhwc=None,
-                 final=True, stop_after_last_bank=False, temb_in=None, attn2_refresh=True, tap=None):
+                 final=True, stop_after_last_bank=False, temb_in=None, attn2_refresh=True, tap=None, attn2_slot=0):
     """UNet3DConditionModel.forward (src/models/unet_3d.py:399-580) / the ReferenceNet
     UNet2DConditionModel.forward (src/models/unet_2d_condition.py:872-1308, f = 1, no motion modules).
 
@@ -446,7 +448,7 @@ def unet_forward(net, cfg, x, b, f, t, ehs, attn2_cache, refs, with_motion, ref_
     Wt, bt, toffs = net.temb_stack([n + ".time_emb_proj" for n in resnet_names(cfg)])
     temb_all = ops.linear_small(emb, Wt, bt, silu_in=True)  # (b, sum Cout) fp32
 
-    a2 = attn2_cache.get(net, cfg, ehs, attn2_refresh)
+    a2 = attn2_cache.get(net, cfg, ehs, attn2_refresh, attn2_slot)
     last_path = attention_paths(cfg)[-1]
 
     def see(p, x):

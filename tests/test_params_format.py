@@ -68,8 +68,9 @@ def test_from_config_filters_and_rejects_unbuilt_variants():
     cfg = dict(C.SD15_UNET_SMALL, _class_name="UNet2DConditionModel", _diffusers_version="0.6.0", some_new_field=1)
     m = UNet3DConditionModel.from_config(cfg, **C.INFERENCE_V2)
     assert m.config.use_motion_module and m.config.motion_module_kwargs["temporal_position_encoding_max_len"] == 32
-    with pytest.raises(NotImplementedError):  # inference_v1.yaml: GroupNorm statistics across frames
-        UNet3DConditionModel(**dict(C.unet3d_kwargs(True), use_inflated_groupnorm=False))
+    # inference_v1.yaml (GroupNorm statistics across frames) is built since round 3
+    v1 = UNet3DConditionModel(**dict(C.unet3d_kwargs(True), use_inflated_groupnorm=False, motion_module_mid_block=False))
+    assert v1.config.use_inflated_groupnorm is False and not any(k.startswith("mid_block.motion") for k in v1.state_dict())
     with pytest.raises(NotImplementedError):
         UNet3DConditionModel(**dict(C.unet3d_kwargs(True), use_linear_projection=True))
 
