@@ -29,6 +29,14 @@
 // LDS: 80 + 32 + 40 = 152 KB -> one block per CU.  Global->LDS traffic per block: 80 KB (x) + 20 x 120 KB (W1, W2).
 #include "common.h"
 
+// GEGLU activation of the epilogues: gelu_poly_f (FMA pipe only; default) or, with -DANIP_GELU_EXACT, gelu_fast_f (A&S erf,
+// |error| <= 1.5e-7, two transcendentals)
+#ifdef ANIP_GELU_EXACT
+#define ANIP_GELU gelu_fast_f
+#else
+#define ANIP_GELU gelu_poly_f
+#endif
+
 namespace {
 
 constexpr uint32_t FFN_OOB = 0xFFFFFFF0u;
@@ -169,7 +177,7 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs a) {
     for (int i = 0; i < 4; ++i) {
       union { u32x2 u; f16 e[4]; } t;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) t.e[r] = (f16)((gacc[i][0][r] + bv[r]) * gelu_fast_f(gacc[i][1][r] + bg[r]));
+      for (int r = 0; r < 4; ++r) t.e[r] = (f16)((gacc[i][0][r] + bv[r]) * ANIP_GELU(gacc[i][1][r] + bg[r]));
       const int row = wm * 64 + i * 16 + fr;
       // hidden unit wn*16 + fq*4 .. +3 of the chunk: 16-B slot (wn*2 + fq/2) ^ (row & 7), byte (fq & 1) * 8 in it
       *(u32x2*)(hs + row * 128 + (((wn * 2 + (fq >> 1)) ^ (row & 7)) << 4) + (fq & 1) * 8) = t.u;

@@ -15,6 +15,14 @@
 // the same A row-panel.
 #include "common.h"
 
+// GEGLU activation of the epilogues: gelu_poly_f (FMA pipe only; default) or, with -DANIP_GELU_EXACT, gelu_fast_f (A&S erf,
+// |error| <= 1.5e-7, two transcendentals)
+#ifdef ANIP_GELU_EXACT
+#define ANIP_GELU gelu_fast_f
+#else
+#define ANIP_GELU gelu_poly_f
+#endif
+
 int anip_gemm2_try(const anip_gemm_params& p, hipStream_t stream);  // gemm2.hip
 int anip_gemm2_try_splitk(const anip_gemm_params& p, hipStream_t stream);
 int64_t anip_gemm2_workspace_bytes(const anip_gemm_params& p);
@@ -226,7 +234,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_small_kernel(const anip_gemm
         for (int e = 0; e < 8; ++e) {
           float hh = hrow[e], gg = grow[e];
           if (p.bias != nullptr && e < nvalid) { hh += p.bias[pn + e]; gg += p.bias[pn + 16 + e]; }
-          v[e] = hh * gelu_fast_f(gg);
+          v[e] = hh * ANIP_GELU(gg);
         }
       } else {
         const float* crow = cs + row * CS + cc * 8;

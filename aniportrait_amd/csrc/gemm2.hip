@@ -27,6 +27,14 @@
 
 #include "common.h"
 
+// GEGLU activation of the epilogues: gelu_poly_f (FMA pipe only; default) or, with -DANIP_GELU_EXACT, gelu_fast_f (A&S erf,
+// |error| <= 1.5e-7, two transcendentals)
+#ifdef ANIP_GELU_EXACT
+#define ANIP_GELU gelu_fast_f
+#else
+#define ANIP_GELU gelu_poly_f
+#endif
+
 namespace {
 
 constexpr uint32_t OOB = 0xFFFFFFF0u;
@@ -831,8 +839,8 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
         float v[8];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float h0 = (acc[i][0][r] * alpha + bv0[r]) * gelu_fast_f(acc[i][1][r] * alpha + bg0[r]);
-          float h1 = (acc[i][2][r] * alpha + bv1[r]) * gelu_fast_f(acc[i][3][r] * alpha + bg1[r]);
+          float h0 = (acc[i][0][r] * alpha + bv0[r]) * ANIP_GELU(acc[i][1][r] * alpha + bg0[r]);
+          float h1 = (acc[i][2][r] * alpha + bv1[r]) * ANIP_GELU(acc[i][3][r] * alpha + bg1[r]);
           row_swap(h0, h1);
           v[r] = h0;
           v[4 + r] = h1;

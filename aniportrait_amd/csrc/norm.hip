@@ -46,9 +46,25 @@ __global__ __launch_bounds__(NT) void gn_stats_kernel(const f16* __restrict__ x1
       const f16* base = second ? x2 : x1;
       const int Cs = second ? C2 : C1;
       const int cc = second ? c - C1 : c;
-      for (int64_t p = p0 + r; p < p1; p += rows_par) {
+      // four independent 16-B loads in flight per thread (one load per trip left ~38 KB per CU in flight: 3.7 TB/s)
+      const f16* src = base + (int64_t)n * HW * Cs + cc;
+      int64_t p = p0 + r;
+      for (; p + 3 * (int64_t)rows_par < p1; p += 4 * (int64_t)rows_par) {
+        U4H8 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u].u = *(const u32x4*)(src + (p + u * (int64_t)rows_par) * Cs);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float f = (float)v[u].e[e];
+            s[e] += f;
+            q[e] += f * f;
+          }
+      }
+      for (; p < p1; p += rows_par) {
         U4H8 v;
-        v.u = *(const u32x4*)(base + ((int64_t)n * HW + p) * Cs + cc);
+        v.u = *(const u32x4*)(src + p * Cs);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float f = (float)v.e[e];
@@ -126,32 +142,57 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const f16* __restrict__ x1
   __syncthreads();
   const int64_t p0 = (int64_t)blockIdx.x * ppc_apply;
   const int64_t p1 = min(HW, p0 + ppc_apply);
-  // walk the (pixel, channel-vector) space with stride NT without per-element divisions
-  const int npix = (int)(p1 - p0);
-  int cv = tid % CV, pp = tid / CV;
-  const int dcv = NT % CV, dpp = NT / CV;
-  for (; pp < npix; pp += dpp, cv += dcv) {
-    if (cv >= CV) {
-      cv -= CV;
-      if (++pp >= npix) break;
+  // thread = (pixel row r of rows_par, channel vector cv): its 8 scale / shift values stay in registers and it walks the
+  // pixels r, r + rows_par, ... with four independent 16-B loads in flight (round 2 walked (pixel, vector) with stride
+  // NT: one dependent load per trip and four LDS reads per vector — 3.4 TB/s)
+  const int rows_par = CV <= NT ? NT / CV : 1;
+  for (int cv0 = 0; cv0 < CV; cv0 += NT) {  // executes once unless C > 2048
+    int cv, r;
+    bool active;
+    if (CV <= NT) {
+      cv = tid % CV;
+      r = tid / CV;
+      active = r < rows_par;
+    } else {
+      cv = cv0 + tid;
+      r = 0;
+      active = cv < CV;
     }
-    const int64_t p = p0 + pp;
+    if (!active) continue;
     const int c = cv << 3;
     const bool second = c >= C1;
-    const f16* src = second ? x2 + ((int64_t)n * HW + p) * C2 + (c - C1) : x1 + ((int64_t)n * HW + p) * C1 + c;
-    U4H8 v, o;
-    v.u = *(const u32x4*)src;
-    const float4 s0 = *(const float4*)(scale + c), s1 = *(const float4*)(scale + c + 4);
-    const float4 h0 = *(const float4*)(shift + c), h1 = *(const float4*)(shift + c + 4);
-    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-    const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+    const f16* src = second ? x2 + (int64_t)n * HW * C2 + (c - C1) : x1 + (int64_t)n * HW * C1 + c;
+    const int Cs = second ? C2 : C1;
+    f16* dst = y + (int64_t)n * HW * C + c;
+    float sc[8], sh[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float f = (float)v.e[e] * sc[e] + sh[e];
-      if (silu) f = silu_f(f);
-      o.e[e] = (f16)f;
+      sc[e] = scale[c + e];
+      sh[e] = shift[c + e];
     }
-    *(u32x4*)(y + ((int64_t)n * HW + p) * C + c) = o.u;
+    auto norm8 = [&](const U4H8& v, f16* out) {
+      U4H8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float f = (float)v.e[e] * sc[e] + sh[e];
+        if (silu) f = silu_f(f);
+        o.e[e] = (f16)f;
+      }
+      *(u32x4*)out = o.u;
+    };
+    int64_t p = p0 + r;
+    for (; p + 3 * (int64_t)rows_par < p1; p += 4 * (int64_t)rows_par) {
+      U4H8 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u].u = *(const u32x4*)(src + (p + u * (int64_t)rows_par) * Cs);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) norm8(v[u], dst + (p + u * (int64_t)rows_par) * C);
+    }
+    for (; p < p1; p += rows_par) {
+      U4H8 v;
+      v.u = *(const u32x4*)(src + p * Cs);
+      norm8(v, dst + p * C);
+    }
   }
 }
 
@@ -438,7 +479,8 @@ extern "C" int anip_groupnorm_frames(const void* x1, int C1, const void* x2, int
   }
   ANIP_LAUNCH_CHECK("anip_groupnorm(stats)");
   // apply: ~2048 pixels*C/8 vectors per block at least, >= 1024 blocks when possible
-  int64_t want = (2048 + N - 1) / N;
+  static const int apply_blocks = getenv("ANIP_GN_APPLY_BLOCKS") ? atoi(getenv("ANIP_GN_APPLY_BLOCKS")) : 1024;  // experiments
+  int64_t want = (apply_blocks + N - 1) / N;
   int64_t maxc = (HW + 15) / 16;
   int64_t ac = want < maxc ? want : maxc;
   if (ac < 1) ac = 1;

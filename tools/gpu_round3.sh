@@ -19,6 +19,20 @@ for STEP in "$@"; do
   case $STEP in
   env:*)      # env:VAR=VALUE — exported for the following steps
     export "${STEP#env:}"; echo "exported ${STEP#env:}" ;;
+  nbench:*)   # nbench:<name> — tools/bench_kernels.py norm family under the current environment -> nbench_<name>.jsonl
+    N=${STEP#nbench:}
+    timeout 300 python tools/bench_kernels.py --only=norm > $OUT/nbench_$N.jsonl 2>&1; echo "rc=$?"
+    python - <<PY
+import json
+for l in open("$OUT/nbench_$N.jsonl"):
+    try: r=json.loads(l)
+    except Exception: continue
+    if "tag" in r: print("%-20s %-16s %8.1f us %7.0f GB/s"%(r["kernel"],r["tag"],r.get("ms",0)*1e3,r.get("gbps",0)))
+PY
+    ;;
+  ntests)
+    timeout 600 python -m pytest tests/test_hip_ops.py -m gpu -q -k "groupnorm or layernorm" > $OUT/ntests.log 2>&1; echo "rc=$?" >> $OUT/ntests.log
+    grep -E "^FAILED|passed|failed|rc=" $OUT/ntests.log | tail -n 8 ;;
   kbench:*)   # kbench:<name> — tools/bench_kernels.py gemm,conv under the current environment -> kbench_<name>.jsonl
     N=${STEP#kbench:}
     timeout 400 python tools/bench_kernels.py --only=gemm,conv > $OUT/kbench_$N.jsonl 2>&1; echo "rc=$?" ;;
