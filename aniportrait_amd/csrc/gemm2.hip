@@ -434,13 +434,30 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
     if (CONV && nk > 1) prepare(kt_begin + 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();
+    if (SCHED != 3 && grp == 1) __builtin_amdgcn_s_barrier();
     f16x8 bf[NB], af[4];
     const int a_lo = a_row_off, a_hi = a_row_off + 64 * RB;
-#define ANIP_G2_BAR()                      \
+    // SCHED 3 (experiment builds only, -DANIP_GEMM2_TIMING; measured 2-5 % slower than SCHED 1 on every wide shape — without
+    // the mid-step rendezvous the two waves of a SIMD drift into computing / loading at the same time): ONE barrier per
+    // sub-step instead of two.  Both wave groups run the same stream L0 C0 L1 C1 ...; group 0
+    // passes a barrier after every COMPUTE, group 1 after every LOAD, so between two barriers one wave of a SIMD runs
+    // [LOAD(s), COMPUTE(s)] while its partner runs [COMPUTE(s-1), LOAD(s)]: first half load || compute, second half
+    // compute || load, with no rendezvous in the middle.  An interval then costs L + C of one wave instead of
+    // 2 x max(L, C) (measured: LOAD 315-580 vs COMPUTE 320-400 cycles, profiles/r03/i_*), and four barrier round trips
+    // per K-tile disappear.  Hazards as above with barrier #s closing sub-step s for both groups: every wait sits in a
+    // LOAD that precedes the barrier the readers pass before they read (RAW), and every re-staged region was last read
+    // at least one barrier earlier (WAR: the tightest pair is A-lo, read last at j=3 of tile t-1, re-staged at j=2 of t).
+    constexpr bool HALF_BAR = (SCHED == 3);
+#define ANIP_G2_BAR_RAW()                  \
     __builtin_amdgcn_sched_barrier(0);     \
     __builtin_amdgcn_s_barrier();          \
     __builtin_amdgcn_sched_barrier(0)
+#define ANIP_G2_BAR_L()                                  \
+    if (!HALF_BAR || grp == 1) { ANIP_G2_BAR_RAW(); }    \
+    else { __builtin_amdgcn_sched_barrier(0); }
+#define ANIP_G2_BAR_C()                                  \
+    if (!HALF_BAR || grp == 0) { ANIP_G2_BAR_RAW(); }    \
+    else { __builtin_amdgcn_sched_barrier(0); }
 #define ANIP_G2_MMA(I0)                                                                                   \
     __builtin_amdgcn_s_setprio(1);                                                                        \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < NB; ++j)          \
@@ -489,11 +506,11 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       }
       ANIP_G2_STAMP(0);
-      ANIP_G2_BAR();
+      ANIP_G2_BAR_L();
       ANIP_G2_STAMP(1);
       ANIP_G2_MMA(0);
       ANIP_G2_STAMP(2);
-      ANIP_G2_BAR();
+      ANIP_G2_BAR_C();
       ANIP_G2_STAMP(3);
       // ---- j = 1: A-hi x B(k-half 0); stage the remaining B blocks
 #pragma unroll
@@ -504,11 +521,11 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       ANIP_G2_STAMP(4);
-      ANIP_G2_BAR();
+      ANIP_G2_BAR_L();
       ANIP_G2_STAMP(5);
       ANIP_G2_MMA(4);
       ANIP_G2_STAMP(6);
-      ANIP_G2_BAR();
+      ANIP_G2_BAR_C();
       ANIP_G2_STAMP(7);
       // ---- j = 2: A-hi x B(k-half 1) (the B fragments are replaced: one set of B registers); stage A-lo of tile t+1
 #pragma unroll
@@ -521,11 +538,11 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       ANIP_G2_STAMP(8);
-      ANIP_G2_BAR();
+      ANIP_G2_BAR_L();
       ANIP_G2_STAMP(9);
       ANIP_G2_MMA(4);
       ANIP_G2_STAMP(10);
-      ANIP_G2_BAR();
+      ANIP_G2_BAR_C();
       ANIP_G2_STAMP(11);
       // ---- j = 3: A-lo x B(k-half 1); stage A-hi of tile t+1; everything of tile t+1 but that must have landed
 #pragma unroll
@@ -539,7 +556,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       }
       ANIP_G2_STAMP(12);
-      ANIP_G2_BAR();
+      ANIP_G2_BAR_L();
       ANIP_G2_STAMP(13);
       ANIP_G2_MMA(0);
       // conv: the scalar operands of tile t+2 (its first part is fired in the next load segment) behind these MFMAs.
@@ -547,10 +564,10 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
       // the main loop waits for DMA data, not for instruction issue; profiles/r03/e_kbench_prepared_operands.jsonl.)
       if (CONV && t + 2 < nk) prepare(kt_begin + t + 2);
       ANIP_G2_STAMP(14);
-      ANIP_G2_BAR();
+      ANIP_G2_BAR_C();
       ANIP_G2_STAMP(15);
     }
-    if (grp == 0) __builtin_amdgcn_s_barrier();
+    if (SCHED != 3 && grp == 0) __builtin_amdgcn_s_barrier();
     if (TIMED && p.workspace != nullptr && blockIdx.x == gridDim.x / 2 && (wave & 3) == 0 && lane == 0) {
       uint32_t* o = (uint32_t*)p.workspace + grp * 32;
 #pragma unroll
@@ -560,7 +577,9 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
 #undef ANIP_G2_STAMP
 #undef ANIP_G2_DMA_A
 #undef ANIP_G2_DMA_B
-#undef ANIP_G2_BAR
+#undef ANIP_G2_BAR_RAW
+#undef ANIP_G2_BAR_L
+#undef ANIP_G2_BAR_C
 #undef ANIP_G2_MMA
   } else if (PHASED) {
     // Role-alternating schedule for the one-block-per-CU wide tiles.  A K-tile is two 32-deep steps; every step is a
@@ -1030,6 +1049,11 @@ template <int BM2, int BN, int NW, int WNW, int BKT, int NST>
 int dispatch_gemm2(const anip_gemm_params& p, hipStream_t stream, int splitk = 1) {
   if constexpr (NST == 2 && BKT == 64 && NW == 8) {
 #ifdef ANIP_GEMM2_TIMING
+    if (gemm2_sched() == 3) {     // one barrier per sub-step: measured 2-5 % SLOWER than SCHED 1 (profiles/r03/t_kbench_*)
+      if (p.conv) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, true, false, 3>(p, stream, splitk);
+      if (p.trans_out) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, true, 3>(p, stream, splitk);
+      return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, false, 3>(p, stream, splitk);
+    }
     if (gemm2_sched() == 2) {
       if (p.conv) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, true, false, 2>(p, stream, splitk);
       return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, false, 2>(p, stream, splitk);
