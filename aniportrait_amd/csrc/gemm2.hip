@@ -93,32 +93,40 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
   const int wm = wave / WNW, wn = wave % WNW;
 
   const int nbm = (p.M + BM2 - 1) / BM2, nbn = (p.N + BN - 1) / BN, nblk = nbm * nbn;
-  int swz;
-  {
-    const int bid = blockIdx.x, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-    swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  // tile index -> (bm, bn).  Few column tiles (every layer with N <= 4 tiles): row-major — consecutive tiles of an XCD
-  // share the A panel.  Many column tiles (GEGLU ff-in N = 5120 / 10240, the 16x16 qkv N = 3840): groups of GM = 8 row
-  // tiles walked column-major inside the group, so that the ~32 tiles an XCD runs at a time are 8 (M) x 4 (N) — 12
-  // operand panels through its L2 instead of 1 + 32 (rocprofv3: the M = 8192, N = 10240, K = 1280 GEGLU GEMM fetched
-  // 884 MB per launch for 131 MB of operands, the weight matrix once per row tile).
-  int bm, bn;
-  {
-    constexpr int GM = 8;
-    // (only when the weight matrix does not fit an XCD's L2 next to the streaming A panels: with a resident W — the
-    // 64x64 ff-in, 1.6 MB — row-major order reads every operand exactly once and measured 4 % faster)
-    if (nbn >= 8 && (int64_t)p.N * p.K * 2 > (2 << 20) && !(dbg & 32)) {
-      const int per = GM * nbn, grp_ = swz / per, first = grp_ * GM, rem = swz - grp_ * per;
-      const int gsz = min(nbm - first, GM);
-      bm = first + rem % gsz;
-      bn = rem / gsz;
-    } else {
-      bm = swz / nbn;
-      bn = swz % nbn;
+  // virtual block id -> tile origin.  A launch with fewer workgroups than tiles (the PERSISTENT form of the quarter-phased
+  // wide tiles, see launch_gemm2) walks vb = blockIdx.x, + gridDim.x, ...: gridDim.x is a multiple of 8 there, so vb & 7 is
+  // the XCD the workgroup runs on and the XCD-aware order below holds for every tile of the walk.
+  auto tile_of = [&](int vb_, int& m0_, int& n0_) {
+    int swz;
+    {
+      const int bid = vb_, q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+      swz = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-  }
-  const int m0 = bm * BM2, n0 = bn * BN;
+    // tile index -> (bm, bn).  Few column tiles (every layer with N <= 4 tiles): row-major — consecutive tiles of an XCD
+    // share the A panel.  Many column tiles (GEGLU ff-in N = 5120 / 10240, the 16x16 qkv N = 3840): groups of GM = 8 row
+    // tiles walked column-major inside the group, so that the ~32 tiles an XCD runs at a time are 8 (M) x 4 (N) — 12
+    // operand panels through its L2 instead of 1 + 32 (rocprofv3: the M = 8192, N = 10240, K = 1280 GEGLU GEMM fetched
+    // 884 MB per launch for 131 MB of operands, the weight matrix once per row tile).
+    int bm, bn;
+    {
+      constexpr int GM = 8;
+      // (only when the weight matrix does not fit an XCD's L2 next to the streaming A panels: with a resident W — the
+      // 64x64 ff-in, 1.6 MB — row-major order reads every operand exactly once and measured 4 % faster)
+      if (nbn >= 8 && (int64_t)p.N * p.K * 2 > (2 << 20) && !(dbg & 32)) {
+        const int per = GM * nbn, grp_ = swz / per, first = grp_ * GM, rem = swz - grp_ * per;
+        const int gsz = min(nbm - first, GM);
+        bm = first + rem % gsz;
+        bn = rem / gsz;
+      } else {
+        bm = swz / nbn;
+        bn = swz % nbn;
+      }
+    }
+    m0_ = bm * BM2;
+    n0_ = bn * BN;
+  };
+  int vb = blockIdx.x, m0, n0;
+  tile_of(vb, m0, n0);
 
   // experiment (ANIP_GEMM2_DBG bits 8-15 = k, bits 16-17 = who): a subset of the blocks sleeps k x 8128 cycles before
   // it starts, to put blocks out of phase (some in their load-heavy main loop while others store).  who = 0: the second
@@ -162,7 +170,9 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
   //           per-K-tile scalar delta.  Fused nearest-2x upsample (3 convs per UNet call): a_v0 = image base pixel index,
   //           a_v1 = packed window origin (y0 + 1) << 16 | (x0 + 1) in the upsampled grid (round 2's computation).
   uint32_t a_v0[NA_I], a_v1[NA_I];
-  int a_g[NA_I];
+  // 16-B chunk (within the K-tile's row) this lane fetches: the swizzle depends on the row inside the instruction's row
+  // group only (the groups start at multiples of 8 / 16 rows), so it is the same for every A instruction of the lane
+  const int a_g = ls ^ swz_of<BKT>(lr);
   // RPI-row block of the A tile that this wave's i-th DMA instruction fills.  SCHED 0: blocks wave*NA_I + i.
   // SCHED 1 (BM2 = 256, 8 waves 2 x 4, NA_I = 4): instructions 0, 1 fill "A-lo" blocks — the first 64 rows of each
   // 128-row wave-row band — and 2, 3 the "A-hi" blocks, so that the two halves can be staged (and waited for) separately.
@@ -171,13 +181,15 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
     const int r = 2 * wave + (i & 1);            // 0..15 within the half
     return (r >> 3) * 16 + (i >> 1) * 8 + (r & 7);
   };
+  uint32_t b_off[NB_I];
+  // (per tile: the persistent form calls it again, in place, once the last K-tile of the running tile has been issued)
+  auto setup_lanes = [&](const int m0_, const int n0_) {
 #pragma unroll
   for (int i = 0; i < NA_I; ++i) {
     const int row = a_blk(i) * RPI + lr;
     const int g = ls ^ swz_of<BKT>(row);
-    const int m = m0 + row;
+    const int m = m0_ + row;
     const bool okm = m < p.M;
-    a_g[i] = g;
     if (CONV) {
       const int hw = p.Hout * p.Wout;
       const int mm = okm ? m : 0;
@@ -200,15 +212,16 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
       a_v1[i] = (okm && p.A2 != nullptr) ? (uint32_t)(((int64_t)m * p.lda2 + g * 8) * 2) : OOB;
     }
   }
-  uint32_t b_off[NB_I];
 #pragma unroll
   for (int i = 0; i < NB_I; ++i) {
     const int j = wave + NW * i;
     const int row = j * RPI + lr;
     const int g = ls ^ swz_of<BKT>(row);
-    const int n = n0 + row;
+    const int n = n0_ + row;
     b_off[i] = (j < NB_TOT && n < p.N) ? (uint32_t)(((int64_t)n * p.ldw + g * 8) * 2) : OOB;
   }
+  };
+  setup_lanes(m0, n0);
   const int my_b = (NB_TOT - wave + NW - 1) / NW;  // B DMA instructions this wave issues (wave-uniform)
 
   // one A / one B DMA instruction of K-tile kt into ring stage `stage`
@@ -234,7 +247,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
         int y = (int)(a_v1[i] >> 16) - 1 + dy, x = (int)(a_v1[i] & 0xFFFFu) - 1 + dx;
         const bool ok = a_v0[i] != 0xFFFFFFFFu && y >= 0 && y < 2 * p.Hin && x >= 0 && x < 2 * p.Win;
         y >>= 1; x >>= 1;
-        vo = ok ? ((a_v0[i] + (uint32_t)(y * p.Win + x)) * (uint32_t)p.Cin + (uint32_t)(c0 + a_g[i] * 8)) * 2u : OOB;
+        vo = ok ? ((a_v0[i] + (uint32_t)(y * p.Win + x)) * (uint32_t)p.Cin + (uint32_t)(c0 + a_g * 8)) * 2u : OOB;
       } else {
         const int delta = (((dy - p.pad) * p.Win + (dx - p.pad)) * p.Cin + c0) * 2;     // scalar
         vo = ((a_v1[i] >> tap) & 1u) ? a_v0[i] + (uint32_t)delta : OOB;
@@ -246,7 +259,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
       uint32_t vo = second ? a_v1[i] : a_v0[i];
       if (ktail) {
         const int klim = second ? p.K - p.K1 : (p.A2 ? p.K1 : p.K);
-        if (kk + a_g[i] * 8 >= klim) vo = OOB;
+        if (kk + a_g * 8 >= klim) vo = OOB;
       }
       if (second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA2, LDS_PTR(sa + a_blk(i) * 1024), 16, vo, (uint32_t)kk * 2u, 0, 0);
       else __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(sa + a_blk(i) * 1024), 16, vo, (uint32_t)kk * 2u, 0, 0);
@@ -290,33 +303,6 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
     return j < NB - 1 ? wn * (NB - 1) * 16 + j * 16 : WNW * (NB - 1) * 16 + wn * 16;
   };
 
-  f32x4 acc[FM][NB];
-#pragma unroll
-  for (int i = 0; i < FM; ++i)
-#pragma unroll
-    for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // "tight" blocks — tile fully inside the output, 16-B accessible operands, alpha == 1: every hot shape of the path —
-  // start the accumulators from the per-column additive terms (bias and, when the block's rows share one row group,
-  // the row-group bias): NB small L2-resident loads that travel with the prologue DMA, no registers, and nothing
-  // left to fetch for them in the epilogue, where loads queue behind the tile's stores (see there).
-  const bool acc_has_bias = !TRANS && !(dbg & 8) && splitk <= 1 && p.alpha == 1.0f && m0 + BM2 <= p.M && n0 + BN <= p.N &&
-                            (p.bias != nullptr || p.rowbias != nullptr) &&
-                            (p.rowbias == nullptr || (((p.ld_rowbias & 3) == 0) && ((((uintptr_t)p.rowbias) & 15) == 0)));
-  const bool rb_uni = acc_has_bias && p.rowbias != nullptr &&
-                      (m0 / p.rows_per_group == (m0 + BM2 - 1) / p.rows_per_group);
-  if (!TRANS && acc_has_bias) {
-    const float* rb_row = rb_uni ? p.rowbias + (int64_t)(m0 / p.rows_per_group) * p.ld_rowbias : nullptr;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const int cb = n0 + tile_c(j) + (lane >> 4) * 4;       // column of acc[.][j][0] in this lane
-      f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (p.bias != nullptr) b = *(const f32x4*)(p.bias + cb);
-      if (rb_uni) b += *(const f32x4*)(rb_row + cb);
-#pragma unroll
-      for (int i = 0; i < FM; ++i) acc[i][j] = b;
-    }
-  }
-
   // K-tile range of this block: all of K, or — split-K, blockIdx.y = slice — one of `splitk` contiguous slices whose
   // fp32 partial tile goes to the workspace (the batch offset of the epilogue) and is reduced by splitk_reduce_kernel
   int kt_begin = 0, nk = (p.K + BKT - 1) / BKT;
@@ -326,274 +312,780 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
     nk = max(0, min(nk - kt_begin, per));
   }
   constexpr bool PHASED = (NST == 2 && KH == 2 && NW == 8);
+  f32x4 acc[FM][NB];
+
+  // ======== quarter-phased schedule (PHASED && SCHED >= 1): state, DMA operand preparation, prologue ========
+  // Quarter-phased schedule (round 3).  Round 2's role-alternating loop below issues the WHOLE next K-tile (8-9 LDS-DMA
+  // instructions per wave, 36 KiB per wave group through the CU's one 64 B/clk address path) inside ONE of its four
+  // load segments per K-tile and drains it (vmcnt(0)) once per K-tile: that segment is ~3x longer than the 32-MFMA
+  // compute segment of the partner wave it is supposed to hide behind, and the matrix pipe waits at the barrier.
+  // Here a K-tile is FOUR sub-steps of 4 x NB MFMAs (a wave's 128 x WTN tile as [A-lo | A-hi] x [k-half 0 | 1]), the
+  // next tile's DMA is dealt over the four load segments — B first half, B second half, A-lo, A-hi: 2-3 instructions
+  // each — and the queue is never drained: counted vmcnt at two points per tile,
+  //   sub-step order   j=0: A-lo x B(kh0)   j=1: A-hi x B(kh0)   j=2: A-hi x B(kh1)   j=3: A-lo x B(kh1)
+  //   LOAD(j) reads    bf, af                af                    bf (replaced), af    af         (ONE set of B registers)
+  //   LOAD(j) stages   B blocks 0,1 of t+1   B blocks 2.. of t+1   A-lo of t+1          A-hi of t+1      (per wave)
+  //   wait before bar  vmcnt(2): A-hi(t)     lgkm                  lgkm                 vmcnt(2): all of t+1 but A-hi
+  // A-hi of tile t+1, staged last, is first read at j=1 of tile t+1 and waited for at the end of LOAD(j=0) there.
+  // Waves 4-7 run one barrier behind waves 0-3 as before (a wave's compute segment coincides with its SIMD partner's
+  // load segment).  Hazards, with barrier #b closing interval I(b); group 0 runs LOAD(s) in I(2s) and COMPUTE(s) in
+  // I(2s+1), group 1 LOAD(s) in I(2s+1), COMPUTE(s) in I(2s+2), s = 4t + j:
+  //   RAW  every wave waits for its own DMA share before a barrier that every reader passes before it reads: the
+  //        j=3 wait of tile t is before #8t+6 (group 0) / #8t+7 (group 1), the first reads of tile t+1 come after
+  //        #8t+7 / #8t+8; the j=0 wait of tile t+1 before #8t+8 / #8t+9, the A-hi reads after #8t+9 / #8t+10.
+  //   WAR  a region of the other stage is re-staged in tile t no earlier than the sub-step that last read it in tile
+  //        t-1 (B: from j=0, read last at j=2; A-lo: j=2, read last at j=3; A-hi: j=3, read last at j=2) — a whole
+  //        K-tile later, and every LOAD ends with lgkmcnt(0) before its barrier.
+  // (First version of this loop: both B fragment sets live, A-hi needed only at j=2.  The 256 x 320 convolution kernel
+  // then sits at 253-256 VGPRs and any extra state spills INTO the loop: 3x slower, profiles/r03/h_*.)
   if constexpr (PHASED && SCHED >= 1) {
-    // Quarter-phased schedule (round 3).  Round 2's role-alternating loop below issues the WHOLE next K-tile (8-9 LDS-DMA
-    // instructions per wave, 36 KiB per wave group through the CU's one 64 B/clk address path) inside ONE of its four
-    // load segments per K-tile and drains it (vmcnt(0)) once per K-tile: that segment is ~3x longer than the 32-MFMA
-    // compute segment of the partner wave it is supposed to hide behind, and the matrix pipe waits at the barrier.
-    // Here a K-tile is FOUR sub-steps of 4 x NB MFMAs (a wave's 128 x WTN tile as [A-lo | A-hi] x [k-half 0 | 1]), the
-    // next tile's DMA is dealt over the four load segments — B first half, B second half, A-lo, A-hi: 2-3 instructions
-    // each — and the queue is never drained: counted vmcnt at two points per tile,
-    //   sub-step order   j=0: A-lo x B(kh0)   j=1: A-hi x B(kh0)   j=2: A-hi x B(kh1)   j=3: A-lo x B(kh1)
-    //   LOAD(j) reads    bf, af                af                    bf (replaced), af    af         (ONE set of B registers)
-    //   LOAD(j) stages   B blocks 0,1 of t+1   B blocks 2.. of t+1   A-lo of t+1          A-hi of t+1      (per wave)
-    //   wait before bar  vmcnt(2): A-hi(t)     lgkm                  lgkm                 vmcnt(2): all of t+1 but A-hi
-    // A-hi of tile t+1, staged last, is first read at j=1 of tile t+1 and waited for at the end of LOAD(j=0) there.
-    // Waves 4-7 run one barrier behind waves 0-3 as before (a wave's compute segment coincides with its SIMD partner's
-    // load segment).  Hazards, with barrier #b closing interval I(b); group 0 runs LOAD(s) in I(2s) and COMPUTE(s) in
-    // I(2s+1), group 1 LOAD(s) in I(2s+1), COMPUTE(s) in I(2s+2), s = 4t + j:
-    //   RAW  every wave waits for its own DMA share before a barrier that every reader passes before it reads: the
-    //        j=3 wait of tile t is before #8t+6 (group 0) / #8t+7 (group 1), the first reads of tile t+1 come after
-    //        #8t+7 / #8t+8; the j=0 wait of tile t+1 before #8t+8 / #8t+9, the A-hi reads after #8t+9 / #8t+10.
-    //   WAR  a region of the other stage is re-staged in tile t no earlier than the sub-step that last read it in tile
-    //        t-1 (B: from j=0, read last at j=2; A-lo: j=2, read last at j=3; A-hi: j=3, read last at j=2) — a whole
-    //        K-tile later, and every LOAD ends with lgkmcnt(0) before its barrier.
-    // (First version of this loop: both B fragment sets live, A-hi needed only at j=2.  The 256 x 320 convolution kernel
-    // then sits at 253-256 VGPRs and any extra state spills INTO the loop: 3x slower, profiles/r03/h_*.)
     static_assert(FM == 8 && NA_I == 4 && NB_TOT % NW == 0, "quarter-phased schedule: 256-row tile, 2 x 4 waves");
-    // DMA operands of the NEXT K-tile are PREPARED inside a compute segment (scalar / vector address arithmetic hides
-    // between the MFMAs) so that a load segment carries only the bare `buffer_load ... lds` instructions: with the
-    // arithmetic inside the load segments those ran 45-126 non-memory instructions each (conv: tap decode, window test,
-    // per-lane select; plain: source select, K-tail test), longer than the 16-20 MFMAs of the partner they hide behind.
-    // Prepared state is SCALAR only (the per-lane part of an A offset is 2-4 VALU operations at the point of issue):
-    //   conv    p_tap (window tap), p_delta (byte offset of (tap, first channel) relative to the window's centre pixel)
-    //   plain   pa_second (second A source), pa_soff (byte offset of the K position inside the source row)
-    //   pb_soff byte offset of the K-tile inside a W row;  p_ktail: the tile crosses K (per-lane K-tail tests, rare)
-    uint32_t pa_soff = 0, pb_soff = 0;
-    int p_tap = 0, p_delta = 0, p_c0 = 0;
-    bool pa_second = false, p_ktail = false;
-    // conv K cursor of the tile to prepare next (no division in the loop): tap, first channel
-    int cv_tap = 0, cv_c0 = 0;
-    if (CONV) {
-      const int k1 = (kt_begin + 1) * BKT;
-      if (p.conv == 2) {
-        const int cb = k1 / 576, r = k1 - cb * 576;
-        cv_tap = r >> 6;
-        cv_c0 = cb * 64 + (r & 63);
-      } else {
-        cv_tap = k1 / p.Cin;
-        cv_c0 = k1 - cv_tap * p.Cin;
-      }
+  }
+  // DMA operands of the NEXT K-tile are PREPARED inside a compute segment (scalar / vector address arithmetic hides
+  // between the MFMAs) so that a load segment carries only the bare `buffer_load ... lds` instructions: with the
+  // arithmetic inside the load segments those ran 45-126 non-memory instructions each (conv: tap decode, window test,
+  // per-lane select; plain: source select, K-tail test), longer than the 16-20 MFMAs of the partner they hide behind.
+  // Prepared state is SCALAR only (the per-lane part of an A offset is 2-4 VALU operations at the point of issue):
+  //   conv    p_tap (window tap), p_delta (byte offset of (tap, first channel) relative to the window's centre pixel)
+  //   plain   pa_second (second A source), pa_soff (byte offset of the K position inside the source row)
+  //   pb_soff byte offset of the K-tile inside a W row;  p_ktail: the tile crosses K (per-lane K-tail tests, rare)
+  uint32_t pa_soff = 0, pb_soff = 0;
+  int p_tap = 0, p_delta = 0, p_c0 = 0;
+  bool pa_second = false, p_ktail = false;
+  // conv K cursor of the tile to prepare next (no division in the loop): tap, first channel
+  int cv_tap = 0, cv_c0 = 0;
+  // conv, K order 2, no upsample (every hot conv): the byte delta of the K-tile's (tap, channel block) relative to the
+  // window's centre pixel advances by one of three constants per K-tile — next tap in the row, next row, next channel
+  // block — so that `prepare` is a handful of scalar adds (round 3's first version recomputed it with divisions and
+  // multiplies from the kernel arguments: 400 cycles behind the MFMAs of every fourth compute segment).
+  const bool cv_fast = CONV && p.conv == 2 && !p.upsample && BKT == 64;
+  int cv_delta = 0;                                                     // delta of the tile to prepare next
+  // the cursor at K-tile kt_begin + 1: in front of the first output tile and of every further tile of a persistent walk
+  auto reset_cursor = [&]() {
+    if (!CONV) return;
+    const int k1 = (kt_begin + 1) * BKT;
+    if (p.conv == 2) {
+      const int cb = k1 / 576, r = k1 - cb * 576;
+      cv_tap = r >> 6;
+      cv_c0 = cb * 64 + (r & 63);
+    } else {
+      cv_tap = k1 / p.Cin;
+      cv_c0 = k1 - cv_tap * p.Cin;
     }
-    // conv, K order 2, no upsample (every hot conv): the byte delta of the K-tile's (tap, channel block) relative to the
-    // window's centre pixel advances by one of three constants per K-tile — next tap in the row, next row, next channel
-    // block — so that `prepare` is a handful of scalar adds (round 3's first version recomputed it with divisions and
-    // multiplies from the kernel arguments: 400 cycles behind the MFMAs of every fourth compute segment).
-    const bool cv_fast = CONV && p.conv == 2 && !p.upsample && BKT == 64;
-    int cv_delta = 0;                                                     // delta of the tile to prepare next
     if (cv_fast) {
       const int dy = cv_tap / 3, dx = cv_tap - dy * 3;
       cv_delta = (((dy - p.pad) * p.Win + (dx - p.pad)) * p.Cin + cv_c0) * 2;
     }
-    auto prepare = [&](int kt) {
-      const int k0 = kt * BKT;
-      p_ktail = k0 + BKT > p.K;
-      pb_soff = (uint32_t)k0 * 2u;
-      if (CONV) {
-        p_tap = cv_tap;
-        p_c0 = cv_c0;
-        if (cv_fast) {
-          p_delta = cv_delta;
-          const bool row_end = cv_tap == 2 || cv_tap == 5;
-          const bool blk_end = cv_tap == 8;
-          const int stepx = p.Cin * 2;                          // tap + 1 inside a row
-          cv_delta += blk_end ? 128 - (2 * p.Win + 2) * stepx   // tap 8 -> tap 0 of the next 64-channel block
-                              : (row_end ? (p.Win - 2) * stepx : stepx);   // tap 2 -> 3, 5 -> 6 / next tap
-          cv_tap = blk_end ? 0 : cv_tap + 1;
-        } else {
-          const int dy = p_tap / 3, dx = p_tap - dy * 3;
-          p_delta = (((dy - p.pad) * p.Win + (dx - p.pad)) * p.Cin + p_c0) * 2;
-          // advance the cursor by one K-tile — value selects only: conditional stores to the two cursor variables get
-          // merged by the compiler into one store through a selected POINTER, which puts them in scratch memory
-          const int c = cv_c0 + BKT;
-          const bool blk = p.conv == 2 ? ((c & 63) == 0) : (c >= p.Cin);   // left the channel block / the tap
-          const int tap1 = cv_tap + (blk ? 1 : 0);
-          const bool wrap9 = p.conv == 2 && tap1 == 9;                       // conv = 2: next 64-channel block
-          cv_tap = wrap9 ? 0 : tap1;
-          cv_c0 = p.conv == 2 ? ((blk && !wrap9) ? c - 64 : c) : (blk ? 0 : c);
-        }
+  };
+  reset_cursor();
+  auto prepare = [&](int kt) {
+    const int k0 = kt * BKT;
+    p_ktail = k0 + BKT > p.K;
+    pb_soff = (uint32_t)k0 * 2u;
+    if (CONV) {
+      p_tap = cv_tap;
+      p_c0 = cv_c0;
+      if (cv_fast) {
+        p_delta = cv_delta;
+        const bool row_end = cv_tap == 2 || cv_tap == 5;
+        const bool blk_end = cv_tap == 8;
+        const int stepx = p.Cin * 2;                          // tap + 1 inside a row
+        cv_delta += blk_end ? 128 - (2 * p.Win + 2) * stepx   // tap 8 -> tap 0 of the next 64-channel block
+                            : (row_end ? (p.Win - 2) * stepx : stepx);   // tap 2 -> 3, 5 -> 6 / next tap
+        cv_tap = blk_end ? 0 : cv_tap + 1;
       } else {
-        pa_second = (p.A2 != nullptr) && (k0 >= p.K1);   // wave-uniform (K1 % BKT == 0)
-        pa_soff = (uint32_t)(pa_second ? k0 - p.K1 : k0) * 2u;
+        const int dy = p_tap / 3, dx = p_tap - dy * 3;
+        p_delta = (((dy - p.pad) * p.Win + (dx - p.pad)) * p.Cin + p_c0) * 2;
+        // advance the cursor by one K-tile — value selects only: conditional stores to the two cursor variables get
+        // merged by the compiler into one store through a selected POINTER, which puts them in scratch memory
+        const int c = cv_c0 + BKT;
+        const bool blk = p.conv == 2 ? ((c & 63) == 0) : (c >= p.Cin);   // left the channel block / the tap
+        const int tap1 = cv_tap + (blk ? 1 : 0);
+        const bool wrap9 = p.conv == 2 && tap1 == 9;                       // conv = 2: next 64-channel block
+        cv_tap = wrap9 ? 0 : tap1;
+        cv_c0 = p.conv == 2 ? ((blk && !wrap9) ? c - 64 : c) : (blk ? 0 : c);
       }
-    };
-    auto fire_a = [&](int stage, int i) {
-      char* dst = smem + stage * STAGE + a_blk(i) * 1024;
-      if (CONV) {
-        uint32_t vo;
-        if (p.upsample) {                    // 3 convs per UNet call: round 2's per-issue arithmetic
-          const int dy = p_tap / 3, dx = p_tap - dy * 3;
-          int y = (int)(a_v1[i] >> 16) - 1 + dy, x = (int)(a_v1[i] & 0xFFFFu) - 1 + dx;
-          const bool ok = a_v0[i] != 0xFFFFFFFFu && y >= 0 && y < 2 * p.Hin && x >= 0 && x < 2 * p.Win;
-          y >>= 1; x >>= 1;
-          vo = ok ? ((a_v0[i] + (uint32_t)(y * p.Win + x)) * (uint32_t)p.Cin + (uint32_t)(p_c0 + a_g[i] * 8)) * 2u : OOB;
-        } else {
-          vo = ((a_v1[i] >> p_tap) & 1u) ? a_v0[i] + (uint32_t)p_delta : OOB;
-        }
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(dst), 16, vo, 0, 0, 0);
+    } else {
+      pa_second = (p.A2 != nullptr) && (k0 >= p.K1);   // wave-uniform (K1 % BKT == 0)
+      pa_soff = (uint32_t)(pa_second ? k0 - p.K1 : k0) * 2u;
+    }
+  };
+  auto fire_a = [&](int stage, int i) {
+    char* dst = smem + stage * STAGE + a_blk(i) * 1024;
+    if (CONV) {
+      uint32_t vo;
+      if (p.upsample) {                    // 3 convs per UNet call: round 2's per-issue arithmetic
+        const int dy = p_tap / 3, dx = p_tap - dy * 3;
+        int y = (int)(a_v1[i] >> 16) - 1 + dy, x = (int)(a_v1[i] & 0xFFFFu) - 1 + dx;
+        const bool ok = a_v0[i] != 0xFFFFFFFFu && y >= 0 && y < 2 * p.Hin && x >= 0 && x < 2 * p.Win;
+        y >>= 1; x >>= 1;
+        vo = ok ? ((a_v0[i] + (uint32_t)(y * p.Win + x)) * (uint32_t)p.Cin + (uint32_t)(p_c0 + a_g * 8)) * 2u : OOB;
       } else {
-        uint32_t vo = pa_second ? a_v1[i] : a_v0[i];
-        if (p_ktail) {                       // rare: K % 64 != 0, last tile only
-          const int klim = pa_second ? p.K - p.K1 : (p.A2 ? p.K1 : p.K);
-          if ((int)(pa_soff >> 1) + a_g[i] * 8 >= klim) vo = OOB;
-        }
-        if (pa_second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA2, LDS_PTR(dst), 16, vo, pa_soff, 0, 0);
-        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(dst), 16, vo, pa_soff, 0, 0);
+        vo = ((a_v1[i] >> p_tap) & 1u) ? a_v0[i] + (uint32_t)p_delta : OOB;
       }
-    };
-    auto fire_b = [&](int stage, int i) {
-      uint32_t vo = b_off[i];
-      if (p_ktail) {                         // rare: K % 64 != 0, last tile only
-        const int row = (wave + NW * i) * RPI + lr;
-        if ((int)(pb_soff >> 1) + (ls ^ swz_of<BKT>(row)) * 8 >= p.K) vo = OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(dst), 16, vo, 0, 0, 0);
+    } else {
+      uint32_t vo = pa_second ? a_v1[i] : a_v0[i];
+      if (p_ktail) {                       // rare: K % 64 != 0, last tile only
+        const int klim = pa_second ? p.K - p.K1 : (p.A2 ? p.K1 : p.K);
+        if ((int)(pa_soff >> 1) + a_g * 8 >= klim) vo = OOB;
       }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(smem + stage * STAGE + A_BYTES + (wave + NW * i) * 1024), 16, vo, pb_soff, 0, 0);
-    };
-    const int grp = wave >> 2;
+      if (pa_second) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA2, LDS_PTR(dst), 16, vo, pa_soff, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, LDS_PTR(dst), 16, vo, pa_soff, 0, 0);
+    }
+  };
+  auto fire_b = [&](int stage, int i) {
+    uint32_t vo = b_off[i];
+    if (p_ktail) {                         // rare: K % 64 != 0, last tile only
+      const int row = (wave + NW * i) * RPI + lr;
+      if ((int)(pb_soff >> 1) + (ls ^ swz_of<BKT>(row)) * 8 >= p.K) vo = OOB;
+    }
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(smem + stage * STAGE + A_BYTES + (wave + NW * i) * 1024), 16, vo, pb_soff, 0, 0);
+  };
+  f16x8 bf[NB], af[4];
+  const int a_lo = a_row_off, a_hi = a_row_off + 64 * RB;
+  // SCHED 3 (experiment builds only, -DANIP_GEMM2_TIMING; measured 2-5 % slower than SCHED 1 on every wide shape — without
+  // the mid-step rendezvous the two waves of a SIMD drift into computing / loading at the same time): ONE barrier per
+  // sub-step instead of two.  Both wave groups run the same stream L0 C0 L1 C1 ...; group 0
+  // passes a barrier after every COMPUTE, group 1 after every LOAD, so between two barriers one wave of a SIMD runs
+  // [LOAD(s), COMPUTE(s)] while its partner runs [COMPUTE(s-1), LOAD(s)]: first half load || compute, second half
+  // compute || load, with no rendezvous in the middle.  An interval then costs L + C of one wave instead of
+  // 2 x max(L, C) (measured: LOAD 315-580 vs COMPUTE 320-400 cycles, profiles/r03/i_*), and four barrier round trips
+  // per K-tile disappear.  Hazards as above with barrier #s closing sub-step s for both groups: every wait sits in a
+  // LOAD that precedes the barrier the readers pass before they read (RAW), and every re-staged region was last read
+  // at least one barrier earlier (WAR: the tightest pair is A-lo, read last at j=3 of tile t-1, re-staged at j=2 of t).
+  constexpr bool HALF_BAR = (SCHED == 3);
+#define ANIP_G2_BAR_RAW()                  \
+  __builtin_amdgcn_sched_barrier(0);     \
+  __builtin_amdgcn_s_barrier();          \
+  __builtin_amdgcn_sched_barrier(0)
+#define ANIP_G2_BAR_L()                                  \
+  if (!HALF_BAR || grp == 1) { ANIP_G2_BAR_RAW(); }    \
+  else { __builtin_amdgcn_sched_barrier(0); }
+#define ANIP_G2_BAR_C()                                  \
+  if (!HALF_BAR || grp == 0) { ANIP_G2_BAR_RAW(); }    \
+  else { __builtin_amdgcn_sched_barrier(0); }
+#define ANIP_G2_MMA(I0)                                                                                   \
+  __builtin_amdgcn_s_setprio(1);                                                                        \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < NB; ++j)          \
+      acc[(I0) + i][j] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[(I0) + i][j], 0, 0, 0) \
+                               : __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[(I0) + i][j], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0)
+#define ANIP_G2_DMA_B(I)                                  \
+  if (CONV) fire_b(nst, I);                             \
+  else issue_b1(kt_begin + t + 1, nst, I)
+#define ANIP_G2_DMA_A(I)                                  \
+  if (CONV) fire_a(nst, I);                             \
+  else issue_a1(kt_begin + t + 1, nst, I)
+  // SCHED == 2 (-DANIP_GEMM2_TIMING builds only): the same loop with s_memtime stamps around every segment and barrier;
+  // waves 0 and 4 of the middle block write, per sub-step j, the summed cycles of [LOAD work, wait at the barrier
+  // closing LOAD, COMPUTE work, wait at the barrier closing COMPUTE] to p.workspace (tools/exp_gemm_timing.py)
+  constexpr bool TIMED = (SCHED == 2);
+  uint32_t tacc[20];      // [4j + {LOAD, barrier, COMPUTE, barrier}], [16 + j]: LOAD up to lgkmcnt(0), the rest of LOAD = DMA wait
+  uint64_t tprev = 0;
+  if (TIMED) {
+#pragma unroll
+    for (int q = 0; q < 20; ++q) tacc[q] = 0;
+    tprev = __builtin_readcyclecounter();
+  }
+#define ANIP_G2_STAMP(Q)                                    \
+  if (TIMED) {                                            \
+    const uint64_t now_ = __builtin_readcyclecounter();   \
+    tacc[Q] += (uint32_t)(now_ - tprev);                  \
+    tprev = now_;                                         \
+  }
+  const int grp = wave >> 2;
+  if constexpr (PHASED && SCHED >= 1) {
     if (nk > 0) issue(kt_begin, 0);
     if (CONV && nk > 1) prepare(kt_begin + 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (SCHED != 3 && grp == 1) __builtin_amdgcn_s_barrier();
-    f16x8 bf[NB], af[4];
-    const int a_lo = a_row_off, a_hi = a_row_off + 64 * RB;
-    // SCHED 3 (experiment builds only, -DANIP_GEMM2_TIMING; measured 2-5 % slower than SCHED 1 on every wide shape — without
-    // the mid-step rendezvous the two waves of a SIMD drift into computing / loading at the same time): ONE barrier per
-    // sub-step instead of two.  Both wave groups run the same stream L0 C0 L1 C1 ...; group 0
-    // passes a barrier after every COMPUTE, group 1 after every LOAD, so between two barriers one wave of a SIMD runs
-    // [LOAD(s), COMPUTE(s)] while its partner runs [COMPUTE(s-1), LOAD(s)]: first half load || compute, second half
-    // compute || load, with no rendezvous in the middle.  An interval then costs L + C of one wave instead of
-    // 2 x max(L, C) (measured: LOAD 315-580 vs COMPUTE 320-400 cycles, profiles/r03/i_*), and four barrier round trips
-    // per K-tile disappear.  Hazards as above with barrier #s closing sub-step s for both groups: every wait sits in a
-    // LOAD that precedes the barrier the readers pass before they read (RAW), and every re-staged region was last read
-    // at least one barrier earlier (WAR: the tightest pair is A-lo, read last at j=3 of tile t-1, re-staged at j=2 of t).
-    constexpr bool HALF_BAR = (SCHED == 3);
-#define ANIP_G2_BAR_RAW()                  \
-    __builtin_amdgcn_sched_barrier(0);     \
-    __builtin_amdgcn_s_barrier();          \
-    __builtin_amdgcn_sched_barrier(0)
-#define ANIP_G2_BAR_L()                                  \
-    if (!HALF_BAR || grp == 1) { ANIP_G2_BAR_RAW(); }    \
-    else { __builtin_amdgcn_sched_barrier(0); }
-#define ANIP_G2_BAR_C()                                  \
-    if (!HALF_BAR || grp == 0) { ANIP_G2_BAR_RAW(); }    \
-    else { __builtin_amdgcn_sched_barrier(0); }
-#define ANIP_G2_MMA(I0)                                                                                   \
-    __builtin_amdgcn_s_setprio(1);                                                                        \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < NB; ++j)          \
-        acc[(I0) + i][j] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[(I0) + i][j], 0, 0, 0) \
-                                 : __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[(I0) + i][j], 0, 0, 0); \
-    __builtin_amdgcn_s_setprio(0)
-#define ANIP_G2_DMA_B(I)                                  \
-    if (CONV) fire_b(nst, I);                             \
-    else issue_b1(kt_begin + t + 1, nst, I)
-#define ANIP_G2_DMA_A(I)                                  \
-    if (CONV) fire_a(nst, I);                             \
-    else issue_a1(kt_begin + t + 1, nst, I)
-    // SCHED == 2 (-DANIP_GEMM2_TIMING builds only): the same loop with s_memtime stamps around every segment and barrier;
-    // waves 0 and 4 of the middle block write, per sub-step j, the summed cycles of [LOAD work, wait at the barrier
-    // closing LOAD, COMPUTE work, wait at the barrier closing COMPUTE] to p.workspace (tools/exp_gemm_timing.py)
-    constexpr bool TIMED = (SCHED == 2);
-    uint32_t tacc[20];      // [4j + {LOAD, barrier, COMPUTE, barrier}], [16 + j]: LOAD up to lgkmcnt(0), the rest of LOAD = DMA wait
-    uint64_t tprev = 0;
-    if (TIMED) {
+  }
+
+  // ======== tile loop: one pass per output tile.  Every form but the persistent one has gridDim.x == nblk: one pass.
+  // Persistent walk (quarter-phased wide tiles, launch_gemm2): once the main loop of a tile is through — every wave past
+  // the closing rendezvous, so no LDS read of the tile is outstanding — a wave recomputes its per-lane source offsets for
+  // the NEXT tile of the walk, issues that tile's first K-tile into stage 0, and only then runs the epilogue: the first
+  // operands of the next tile arrive under the stores of this one, and a tile starts without the workgroup launch, the
+  // kernel-argument loads and the exposed HBM round trip of a fresh workgroup (5-14 % of a K <= 1280 tile).
+  for (;;) {
+    const int vbn = vb + (int)gridDim.x;
+    const bool has_next = (PHASED && SCHED >= 1) && vbn < nblk;   // block-uniform
+    int m0n = 0, n0n = 0;
 #pragma unroll
-      for (int q = 0; q < 20; ++q) tacc[q] = 0;
-      tprev = __builtin_readcyclecounter();
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // "tight" blocks — tile fully inside the output, 16-B accessible operands, alpha == 1: every hot shape of the path —
+    // start the accumulators from the per-column additive terms (bias and, when the block's rows share one row group,
+    // the row-group bias): NB small L2-resident loads that travel with the prologue DMA, no registers, and nothing
+    // left to fetch for them in the epilogue, where loads queue behind the tile's stores (see there).
+    const bool acc_has_bias = !TRANS && !(dbg & 8) && splitk <= 1 && p.alpha == 1.0f && m0 + BM2 <= p.M && n0 + BN <= p.N &&
+                              (p.bias != nullptr || p.rowbias != nullptr) &&
+                              (p.rowbias == nullptr || (((p.ld_rowbias & 3) == 0) && ((((uintptr_t)p.rowbias) & 15) == 0)));
+    const bool rb_uni = acc_has_bias && p.rowbias != nullptr &&
+                        (m0 / p.rows_per_group == (m0 + BM2 - 1) / p.rows_per_group);
+    if (!TRANS && acc_has_bias) {
+      const float* rb_row = rb_uni ? p.rowbias + (int64_t)(m0 / p.rows_per_group) * p.ld_rowbias : nullptr;
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int cb = n0 + tile_c(j) + (lane >> 4) * 4;       // column of acc[.][j][0] in this lane
+        f32x4 b = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.bias != nullptr) b = *(const f32x4*)(p.bias + cb);
+        if (rb_uni) b += *(const f32x4*)(rb_row + cb);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) acc[i][j] = b;
+      }
     }
-#define ANIP_G2_STAMP(Q)                                    \
-    if (TIMED) {                                            \
-      const uint64_t now_ = __builtin_readcyclecounter();   \
-      tacc[Q] += (uint32_t)(now_ - tprev);                  \
-      tprev = now_;                                         \
+
+    if constexpr (PHASED && SCHED >= 1) {
+      // K-tile 0 (issued in front of the tile loop / in front of the previous tile's epilogue) has landed for every wave;
+      // on a later tile of a walk the counter also covers the previous tile's stores (in order: they were issued later)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (SCHED != 3 && grp == 1) __builtin_amdgcn_s_barrier();
+      for (int t = 0; t < nk; ++t) {
+        const char* sa = smem + (t & 1) * STAGE;
+        const char* sb = sa + A_BYTES;
+        const int nst = (t + 1) & 1;
+        const bool more = t + 1 < nk;                 // block-uniform
+        // ---- j = 0: A-lo x B(k-half 0); stage B blocks 0, 1 of tile t+1; A-hi of THIS tile must have landed
+#pragma unroll
+        for (int j = 0; j < NB; ++j) bf[j] = *(const f16x8*)(sb + (tile_c(j) + fr) * RB + koff[0]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *(const f16x8*)(sa + a_lo + i * 16 * RB + koff[0]);
+        if (more) {
+          ANIP_G2_DMA_B(0);
+          ANIP_G2_DMA_B(1);
+          if (TIMED) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ANIP_G2_STAMP(16); }
+          asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");   // leaves the 2 B blocks just issued: A-hi(t) landed
+        } else {
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        ANIP_G2_STAMP(0);
+        ANIP_G2_BAR_L();
+        ANIP_G2_STAMP(1);
+        ANIP_G2_MMA(0);
+        ANIP_G2_STAMP(2);
+        ANIP_G2_BAR_C();
+        ANIP_G2_STAMP(3);
+        // ---- j = 1: A-hi x B(k-half 0); stage the remaining B blocks
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *(const f16x8*)(sa + a_hi + i * 16 * RB + koff[0]);
+        if (more) {
+#pragma unroll
+          for (int i = 2; i < NB_I; ++i) { ANIP_G2_DMA_B(i); }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ANIP_G2_STAMP(4);
+        ANIP_G2_BAR_L();
+        ANIP_G2_STAMP(5);
+        ANIP_G2_MMA(4);
+        ANIP_G2_STAMP(6);
+        ANIP_G2_BAR_C();
+        ANIP_G2_STAMP(7);
+        // ---- j = 2: A-hi x B(k-half 1) (the B fragments are replaced: one set of B registers); stage A-lo of tile t+1
+#pragma unroll
+        for (int j = 0; j < NB; ++j) bf[j] = *(const f16x8*)(sb + (tile_c(j) + fr) * RB + koff[1]);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *(const f16x8*)(sa + a_hi + i * 16 * RB + koff[1]);
+        if (more) {
+          ANIP_G2_DMA_A(0);
+          ANIP_G2_DMA_A(1);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        ANIP_G2_STAMP(8);
+        ANIP_G2_BAR_L();
+        ANIP_G2_STAMP(9);
+        ANIP_G2_MMA(4);
+        ANIP_G2_STAMP(10);
+        ANIP_G2_BAR_C();
+        ANIP_G2_STAMP(11);
+        // ---- j = 3: A-lo x B(k-half 1); stage A-hi of tile t+1; everything of tile t+1 but that must have landed
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *(const f16x8*)(sa + a_lo + i * 16 * RB + koff[1]);
+        if (more) {
+          ANIP_G2_DMA_A(2);
+          ANIP_G2_DMA_A(3);
+          if (TIMED) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ANIP_G2_STAMP(19); }
+          asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        }
+        ANIP_G2_STAMP(12);
+        ANIP_G2_BAR_L();
+        ANIP_G2_STAMP(13);
+        ANIP_G2_MMA(0);
+        // conv: the scalar operands of tile t+2 (its first part is fired in the next load segment) behind these MFMAs.
+        // (The plain GEMM issues with its per-instruction arithmetic in place: hoisting it measured 4-6 % SLOWER —
+        // the main loop waits for DMA data, not for instruction issue; profiles/r03/e_kbench_prepared_operands.jsonl.)
+        if (CONV && t + 2 < nk) prepare(kt_begin + t + 2);
+        ANIP_G2_STAMP(14);
+        ANIP_G2_BAR_C();
+        ANIP_G2_STAMP(15);
+      }
+      if (SCHED != 3 && grp == 0) __builtin_amdgcn_s_barrier();   // closing rendezvous: group 1 has finished its last LOAD
+      if (has_next) {
+        tile_of(vbn, m0n, n0n);
+        setup_lanes(m0n, n0n);
+        issue(kt_begin, 0);
+        if (CONV && nk > 1) {
+          reset_cursor();
+          prepare(kt_begin + 1);
+        }
+      }
+    } else if (PHASED) {
+      // Role-alternating schedule for the one-block-per-CU wide tiles.  A K-tile is two 32-deep steps; every step is a
+      // LOAD segment (all ds_reads of the step's fragments, plus the DMA issue of the next K-tile on the first step)
+      // and a COMPUTE segment (FM x NB MFMAs on registers only), each closed by an s_barrier.  Waves 4-7 run one
+      // barrier behind waves 0-3 (they execute one extra barrier up front, waves 0-3 one at the end), so on every SIMD
+      // — waves w and w+4 share one — a wave's COMPUTE segment always coincides with its partner's LOAD segment: the
+      // matrix pipe never waits for LDS or for the barrier.
+      //   barrier numbering: group 0 passes #2s after LOAD(s) and #2s+1 after COMPUTE(s); group 1 passes #2s+1 after
+      //   LOAD(s) and #2s+2 after COMPUTE(s).  K-tile t+1 is issued in LOAD(2t) (its stage was last read in LOAD(2t-1),
+      //   complete before #4t-1) and every wave drains its DMA before #4t+3, after which the first reads of tile t+1 follow.
+      const int grp = wave >> 2;
+      if (nk > 0) issue(kt_begin, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (grp == 1) __builtin_amdgcn_s_barrier();
+      for (int s2 = 0; s2 < 2 * nk; ++s2) {
+        const int t = s2 >> 1, kh = s2 & 1;
+        if (kh == 0 && t + 1 < nk) issue(kt_begin + t + 1, (t + 1) & 1);
+        const char* sa = smem + (t & 1) * STAGE;
+        const char* sb = sa + A_BYTES;
+        const int ko = kh ? koff[KH - 1] : koff[0];
+        f16x8 af[FM], bf[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) bf[j] = *(const f16x8*)(sb + (tile_c(j) + fr) * RB + ko);
+#pragma unroll
+        for (int i = 0; i < FM; ++i) af[i] = *(const f16x8*)(sa + a_row_off + i * 16 * RB + ko);
+        if (grp == 1 && kh == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#ifdef ANIP_GEMM2_EXPERIMENTS
+        if (!(dbg & 4))
+#endif
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+              acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0)
+                                : __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (grp == 0 && kh == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (grp == 0) __builtin_amdgcn_s_barrier();
+    } else {
+#pragma unroll
+      for (int t = 0; t < NST - 1; ++t)
+        if (t < nk) issue(kt_begin + t, t);
+      for (int kt = 0; kt < nk; ++kt) {
+        // this wave's part of tile kt has landed; later tiles (if any were issued) stay in flight
+        if (NST > 2 && kt + 1 < nk) {
+          if (my_b == NB_I) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (NA_I + NB_I)) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (NA_I + NB_I - 1)) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();  // tile kt is complete for all waves; the stage read at kt-1 is free
+        if (kt + NST - 1 < nk) issue(kt_begin + kt + NST - 1, (kt + NST - 1) % NST);
+        const char* sa = smem + (kt % NST) * STAGE;
+        const char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int kh = 0; kh < KH; ++kh) {
+          f16x8 bf[NB];
+#pragma unroll
+          for (int t = 0; t < NB; ++t) bf[t] = *(const f16x8*)(sb + (tile_c(t) + fr) * RB + koff[kh]);
+#pragma unroll
+          for (int i = 0; i < FM; ++i) {
+            const f16x8 af = *(const f16x8*)(sa + a_row_off + i * 16 * RB + koff[kh]);
+#ifdef ANIP_GEMM2_EXPERIMENTS
+            if (!(dbg & 4))      // experiment: no MFMAs
+#endif
+#pragma unroll
+              for (int j = 0; j < NB; ++j)
+                acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0)
+                                  : __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af, acc[i][j], 0, 0, 0);
+          }
+        }
+      }
     }
-    for (int t = 0; t < nk; ++t) {
-      const char* sa = smem + (t & 1) * STAGE;
-      const char* sb = sa + A_BYTES;
-      const int nst = (t + 1) & 1;
-      const bool more = t + 1 < nk;                 // block-uniform
-      // ---- j = 0: A-lo x B(k-half 0); stage B blocks 0, 1 of tile t+1; A-hi of THIS tile must have landed
+
+    // ---- epilogue: straight from the accumulators ------------------------------------------------------
+    //   !TRANS: acc[i][j][r] = C[m0 + wm*WTM + i*16 + fr][n0 + wn*WTN + j*16 + fq*4 + r]
+    //    TRANS: acc[i][j][r] = C[m0 + wm*WTM + i*16 + fq*4 + r][n0 + wn*WTN + j*16 + fr]
+    if (dbg & 1) {           // experiment: no epilogue (keep the accumulators live)
 #pragma unroll
-      for (int j = 0; j < NB; ++j) bf[j] = *(const f16x8*)(sb + (tile_c(j) + fr) * RB + koff[0]);
+      for (int i = 0; i < FM; ++i)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *(const f16x8*)(sa + a_lo + i * 16 * RB + koff[0]);
-      if (more) {
-        ANIP_G2_DMA_B(0);
-        ANIP_G2_DMA_B(1);
-        if (TIMED) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ANIP_G2_STAMP(16); }
-        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");   // leaves the 2 B blocks just issued: A-hi(t) landed
+        for (int j = 0; j < NB; ++j) asm volatile("" ::"v"(acc[i][j]));
+      return;               // (ends a persistent walk, too)
+    }
+    const float alpha = p.alpha;
+    const int64_t obatch = (p.batch > 1) ? (int64_t)blockIdx.y * p.strideO : 0;
+    const int tsel = fq & 1, csel = (fq >> 1) * 8;   // after row_swap: tile of the pair / column offset in it
+
+    // 8 consecutive output columns [n, n+8) of row m: bias / row-group bias / residual / store
+    // (add_bias / add_rb: false when the accumulators were started from that term — acc_has_bias / rb_uni above)
+    auto emit8 = [&](int m, int n, int ncols, float (&v)[8], bool add_bias, bool add_rb, bool add_res) {
+      if (m >= p.M) return;
+      const int nvalid = min(8, ncols - n);
+      if (nvalid <= 0) return;
+      if (add_bias && p.bias != nullptr) {
+        if (nvalid == 8) {
+          const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 4);
+          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+          v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (e < nvalid) v[e] += p.bias[n + e];
+        }
+      }
+      if (add_rb && p.rowbias != nullptr) {
+        const float* rbp = p.rowbias + ((int64_t)m / p.rows_per_group) * p.ld_rowbias + n;
+        if (nvalid == 8 && ((p.ld_rowbias & 3) == 0) && (((uintptr_t)p.rowbias & 15) == 0)) {
+          const float4 b0 = *(const float4*)rbp, b1 = *(const float4*)(rbp + 4);
+          v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+          v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (e < nvalid) v[e] += rbp[e];
+        }
+      }
+      if (add_res && p.residual != nullptr) {
+        const f16* rp = (const f16*)p.residual + (int64_t)m * p.ldr + n;
+        if (nvalid == 8 && ((p.ldr & 7) == 0)) {
+          U4H8 t;
+          t.u = *(const u32x4*)rp;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += (float)t.e[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (e < nvalid) v[e] += (float)rp[e];
+        }
+      }
+      const int64_t o = p.head_dim > 0 ? ((int64_t)(n / p.head_dim) * p.M + m) * p.head_dim + n % p.head_dim
+                                       : obatch + (int64_t)m * p.ldo + n;
+      const int64_t ldo_eff = p.head_dim > 0 ? p.head_dim : p.ldo;
+      if (p.out_f32) {
+        float* op = (float*)p.out + o;
+        if (nvalid == 8 && ((p.ldo & 3) == 0)) {
+          *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
+          *(float4*)(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (e < nvalid) op[e] = v[e];
+        }
       } else {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        f16* op = (f16*)p.out + o;
+        if (nvalid == 8 && ((ldo_eff & 7) == 0)) {
+          U4H8 t;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) t.e[e] = (f16)v[e];
+          *(u32x4*)op = t.u;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (e < nvalid) op[e] = (f16)v[e];
+        }
       }
-      ANIP_G2_STAMP(0);
-      ANIP_G2_BAR_L();
-      ANIP_G2_STAMP(1);
-      ANIP_G2_MMA(0);
-      ANIP_G2_STAMP(2);
-      ANIP_G2_BAR_C();
-      ANIP_G2_STAMP(3);
-      // ---- j = 1: A-hi x B(k-half 0); stage the remaining B blocks
+    };
+    // 4 consecutive output columns (the unpaired last tile when BN/32 is odd)
+    auto emit4 = [&](int m, int n, float (&v)[4], bool add_bias, bool add_rb) {
+      if (m >= p.M) return;
+      const int nvalid = min(4, p.N - n);
+      if (nvalid <= 0) return;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *(const f16x8*)(sa + a_hi + i * 16 * RB + koff[0]);
-      if (more) {
-#pragma unroll
-        for (int i = 2; i < NB_I; ++i) { ANIP_G2_DMA_B(i); }
+      for (int e = 0; e < 4; ++e) {
+        if (e < nvalid) {
+          if (add_bias && p.bias != nullptr) v[e] += p.bias[n + e];
+          if (add_rb && p.rowbias != nullptr) v[e] += p.rowbias[((int64_t)m / p.rows_per_group) * p.ld_rowbias + n + e];
+        }
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      ANIP_G2_STAMP(4);
-      ANIP_G2_BAR_L();
-      ANIP_G2_STAMP(5);
-      ANIP_G2_MMA(4);
-      ANIP_G2_STAMP(6);
-      ANIP_G2_BAR_C();
-      ANIP_G2_STAMP(7);
-      // ---- j = 2: A-hi x B(k-half 1) (the B fragments are replaced: one set of B registers); stage A-lo of tile t+1
+      if (p.residual != nullptr) {
+        const f16* rp = (const f16*)p.residual + (int64_t)m * p.ldr + n;
+        if (nvalid == 4 && ((p.ldr & 3) == 0)) {
+          union { u32x2 u; f16 e[4]; } t;
+          t.u = *(const u32x2*)rp;
 #pragma unroll
-      for (int j = 0; j < NB; ++j) bf[j] = *(const f16x8*)(sb + (tile_c(j) + fr) * RB + koff[1]);
+          for (int e = 0; e < 4; ++e) v[e] += (float)t.e[e];
+        } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *(const f16x8*)(sa + a_hi + i * 16 * RB + koff[1]);
-      if (more) {
-        ANIP_G2_DMA_A(0);
-        ANIP_G2_DMA_A(1);
+          for (int e = 0; e < 4; ++e)
+            if (e < nvalid) v[e] += (float)rp[e];
+        }
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      ANIP_G2_STAMP(8);
-      ANIP_G2_BAR_L();
-      ANIP_G2_STAMP(9);
-      ANIP_G2_MMA(4);
-      ANIP_G2_STAMP(10);
-      ANIP_G2_BAR_C();
-      ANIP_G2_STAMP(11);
-      // ---- j = 3: A-lo x B(k-half 1); stage A-hi of tile t+1; everything of tile t+1 but that must have landed
+      const int64_t o = p.head_dim > 0 ? ((int64_t)(n / p.head_dim) * p.M + m) * p.head_dim + n % p.head_dim
+                                       : obatch + (int64_t)m * p.ldo + n;
+      const int64_t ldo_eff = p.head_dim > 0 ? p.head_dim : p.ldo;
+      if (p.out_f32) {
+        float* op = (float*)p.out + o;
+        if (nvalid == 4 && ((p.ldo & 3) == 0)) *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
+        else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *(const f16x8*)(sa + a_lo + i * 16 * RB + koff[1]);
-      if (more) {
-        ANIP_G2_DMA_A(2);
-        ANIP_G2_DMA_A(3);
-        if (TIMED) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ANIP_G2_STAMP(19); }
-        asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+          for (int e = 0; e < 4; ++e)
+            if (e < nvalid) op[e] = v[e];
+        }
       } else {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        f16* op = (f16*)p.out + o;
+        if (nvalid == 4 && ((ldo_eff & 3) == 0)) {
+          union { u32x2 u; f16 e[4]; } t;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t.e[e] = (f16)v[e];
+          *(u32x2*)op = t.u;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (e < nvalid) op[e] = (f16)v[e];
+        }
       }
-      ANIP_G2_STAMP(12);
-      ANIP_G2_BAR_L();
-      ANIP_G2_STAMP(13);
-      ANIP_G2_MMA(0);
-      // conv: the scalar operands of tile t+2 (its first part is fired in the next load segment) behind these MFMAs.
-      // (The plain GEMM issues with its per-instruction arithmetic in place: hoisting it measured 4-6 % SLOWER —
-      // the main loop waits for DMA data, not for instruction issue; profiles/r03/e_kbench_prepared_operands.jsonl.)
-      if (CONV && t + 2 < nk) prepare(kt_begin + t + 2);
-      ANIP_G2_STAMP(14);
-      ANIP_G2_BAR_C();
-      ANIP_G2_STAMP(15);
+    };
+
+    if (TRANS) {
+      // out[n][m], m contiguous: pair the tiles (i, i+1) along M; bias only (checked by the launcher)
+      float bt[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {       // all bias loads in front of the first store
+        const int n = n0 + tile_c(j) + fr;
+        bt[j] = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        const int n = n0 + tile_c(j) + fr;
+        const float bn_ = bt[j];
+#pragma unroll
+        for (int ip = 0; ip < FM / 2; ++ip) {
+          float x[4], y[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            x[r] = acc[2 * ip][j][r] * alpha + bn_;
+            y[r] = acc[2 * ip + 1][j][r] * alpha + bn_;
+            row_swap(x[r], y[r]);
+          }
+          const int m = m0 + wm * WTM + (2 * ip + tsel) * 16 + csel;
+          if (n < p.N && m < p.M) {
+            f16* op = (f16*)p.out + obatch + (int64_t)n * p.ldo + m;
+            if (m + 8 <= p.M && ((p.ldo & 7) == 0)) {
+              U4H8 t;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) { t.e[r] = (f16)x[r]; t.e[4 + r] = (f16)y[r]; }
+              *(u32x4*)op = t.u;
+            } else {
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                if (m + r < p.M) op[r] = (f16)x[r];
+                if (m + 4 + r < p.M) op[4 + r] = (f16)y[r];
+              }
+            }
+          }
+        }
+      }
+    } else if (p.act == 1) {
+      // GEGLU: packed columns per 32 = [16 x value | 16 x gate] -> tiles (2t, 2t+1) of a wave are the value / gate
+      // of the same 16 output columns; out column = packed column / 2
+      if (NB == 4) {
+        const int pn = n0 + wn * WTN + fq * 4;          // packed column of acc[i][0][0]
+        float bv0[4], bg0[4], bv1[4], bg1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool hb = p.bias != nullptr && !acc_has_bias;
+          bv0[r] = (hb && pn + r < p.N) ? p.bias[pn + r] : 0.f;
+          bg0[r] = (hb && pn + 16 + r < p.N) ? p.bias[pn + 16 + r] : 0.f;
+          bv1[r] = (hb && pn + 32 + r < p.N) ? p.bias[pn + 32 + r] : 0.f;
+          bg1[r] = (hb && pn + 48 + r < p.N) ? p.bias[pn + 48 + r] : 0.f;
+        }
+        const int ocol = (n0 + wn * WTN) / 2 + tsel * 16 + csel;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          float v[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float h0 = (acc[i][0][r] * alpha + bv0[r]) * ANIP_GELU(acc[i][1][r] * alpha + bg0[r]);
+            float h1 = (acc[i][2][r] * alpha + bv1[r]) * ANIP_GELU(acc[i][3][r] * alpha + bg1[r]);
+            row_swap(h0, h1);
+            v[r] = h0;
+            v[4 + r] = h1;
+          }
+          emit8(m0 + wm * WTM + i * 16 + fr, ocol, p.N / 2, v, false, false, false);
+        }
+      }
+    } else {
+      // A block whose tile lies fully inside the output and whose operands allow 16-B accesses (every hot shape of the
+      // path) takes the tight epilogue below; ragged tiles take the general per-element-guarded one.
+      const bool has_rb = p.rowbias != nullptr, has_res = p.residual != nullptr;
+      // (32-bit per-lane byte offsets: the output / residual extents must stay below 4 GiB)
+      const bool tight = !(dbg & 8) && p.alpha == 1.0f && m0 + BM2 <= p.M && n0 + BN <= p.N &&
+                         (p.out_f32 ? (p.ldo & 3) == 0 : ((p.head_dim > 0 ? p.head_dim : p.ldo) & 7) == 0) &&
+                         (!has_res || (p.ldr & 7) == 0) &&
+                         (acc_has_bias || (p.bias == nullptr && !has_rb)) &&
+                         (int64_t)p.M * p.ldo * (p.out_f32 ? 4 : 2) < (1ll << 32) &&
+                         (!has_res || (int64_t)p.M * p.ldr * 2 < (1ll << 32));
+      if (!tight) {
+        // general path.  The accumulators may ALREADY hold the bias (and a block-uniform row-group bias): a full tile with
+        // 16-B accessible bias terms takes `acc_has_bias` whether or not the rest of the tight conditions hold (output of
+        // 4 GiB or more, unaligned leading dimensions).  Round 2 added them a second time here — the decoded frames of a
+        // 16-frame VAE batch at 512x512 / 768x768 (2^30+ output elements in the upsampler convs) carried every channel's
+        // bias twice: the "46 dB at 512x512, 38 dB at 768x768" of the round-2 / round-3 parity runs.
+        const bool add_bias = !acc_has_bias, add_rb = !(acc_has_bias && rb_uni);
+#pragma unroll
+        for (int jp = 0; jp < NB / 2; ++jp) {
+          const int n = n0 + tile_c(2 * jp) + tsel * 16 + csel;
+#pragma unroll
+          for (int i = 0; i < FM; ++i) {
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float x = acc[i][2 * jp][r] * alpha, y = acc[i][2 * jp + 1][r] * alpha;
+              row_swap(x, y);
+              v[r] = x;
+              v[4 + r] = y;
+            }
+            emit8(m0 + wm * WTM + i * 16 + fr, n, p.N, v, add_bias, add_rb, true);
+          }
+        }
+        if (NB & 1) {
+          const int n = n0 + tile_c(NB - 1) + fq * 4;
+#pragma unroll
+          for (int i = 0; i < FM; ++i) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[i][NB - 1][r] * alpha;
+            emit4(m0 + wm * WTM + i * 16 + fr, n, v, add_bias, add_rb);
+          }
+        }
+      } else {
+        // Residual vectors in batches AHEAD of the stores.  `out` may alias anything as far as the compiler knows, so a
+        // load written after a store stays after it: fetched where they are used (the general path), every (row block,
+        // column pair) pays a dependent L2 / HBM round trip behind the previous stores — FM * NB/2 of them per wave with
+        // one KiB in flight each, which capped the K = 320 / 640 layers at ~2.5 TB/s.  Here RBAT residual vectors of a
+        // column pair are in flight together before the first of their stores; bias and block-uniform row-group bias
+        // are already inside the accumulators.  (RBAT: what the 128-VGPR budget of the 4-waves-per-SIMD tiles allows.)
+        constexpr int RBAT = (NW == 8 && WNW == 2 && NB == 5) ? 2 : FM;   // 256 x 160, 4 waves per SIMD: 128 VGPRs
+        // addressing: wave-uniform 64-bit bases (+ the uniform 16-row step) in SGPRs, one 32-bit per-lane BYTE offset —
+        // 64-bit per-lane pointers for every (row block, column pair) do not fit the 128-VGPR budget next to the
+        // accumulators
+        const int mrow = m0 + wm * WTM + fr;                 // row of acc[0][.]; tile i is 16 rows further down
+        const uint32_t esz = p.out_f32 ? 4u : 2u;
+        const bool hm = p.head_dim > 0;      // head-major output: row step = head_dim, plus a per-column head offset
+        const uint32_t ldr_b = (uint32_t)p.ldr * 2u, ldo_b = (uint32_t)(hm ? p.head_dim : p.ldo) * esz;
+        const char* resb = (const char*)p.residual;
+        char* outb = (char*)p.out + obatch * (int64_t)esz;
+        const uint32_t rrow = (uint32_t)mrow * ldr_b, orow = (uint32_t)mrow * ldo_b;
+        const bool rb_row = has_rb && !rb_uni;               // row-group bias that changes inside the block (rare)
+#pragma unroll
+        for (int jp = 0; jp < NB / 2; ++jp) {
+          const int n = n0 + tile_c(2 * jp) + tsel * 16 + csel;
+          const uint32_t rn = rrow + (uint32_t)n * 2u;
+          const uint32_t on = orow + (hm ? ((uint32_t)(n / p.head_dim) * (uint32_t)p.M * (uint32_t)p.head_dim +
+                                            (uint32_t)(n % p.head_dim)) : (uint32_t)n) * esz;
+#pragma unroll
+          for (int ib = 0; ib < FM; ib += RBAT) {
+            U4H8 res[RBAT];
+            if (has_res) {
+#pragma unroll
+              for (int i = 0; i < RBAT; ++i) res[i].u = *(const u32x4*)(resb + (size_t)((ib + i) * 16) * ldr_b + rn);
+            } else if (PHASED && SCHED >= 1) {   // (defined either way: an undefined value becomes loop-carried state of the tile loop)
+#pragma unroll
+              for (int i = 0; i < RBAT; ++i) res[i].u = u32x4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int ii = 0; ii < RBAT; ++ii) {
+              const int i = ib + ii;
+              float v[8];
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                float x = acc[i][2 * jp][r], y = acc[i][2 * jp + 1][r];
+                row_swap(x, y);
+                v[r] = x;
+                v[4 + r] = y;
+              }
+              if (rb_row) {
+                const float* rbp = p.rowbias + ((int64_t)(mrow + i * 16) / p.rows_per_group) * p.ld_rowbias + n;
+                const float4 b0 = *(const float4*)rbp, b1 = *(const float4*)(rbp + 4);
+                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+                v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+              }
+              if (has_res) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)res[ii].e[e];
+              }
+              char* op = outb + (size_t)(i * 16) * ldo_b + on;
+              if (p.out_f32) {
+                *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
+                *(float4*)(op + 16) = make_float4(v[4], v[5], v[6], v[7]);
+              } else {
+                U4H8 t;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t.e[e] = (f16)v[e];
+                *(u32x4*)op = t.u;
+              }
+            }
+          }
+        }
+        if (NB & 1) {
+          const int n = n0 + tile_c(NB - 1) + fq * 4;
+          const uint32_t rn = rrow + (uint32_t)n * 2u;
+          const uint32_t on = orow + (hm ? ((uint32_t)(n / p.head_dim) * (uint32_t)p.M * (uint32_t)p.head_dim +
+                                            (uint32_t)(n % p.head_dim)) : (uint32_t)n) * esz;
+          union H4 { u32x2 u; f16 e[4]; };
+#pragma unroll
+          for (int ib = 0; ib < FM; ib += RBAT) {
+            H4 res[RBAT];
+            if (has_res) {
+#pragma unroll
+              for (int i = 0; i < RBAT; ++i) res[i].u = *(const u32x2*)(resb + (size_t)((ib + i) * 16) * ldr_b + rn);
+            } else if (PHASED && SCHED >= 1) {
+#pragma unroll
+              for (int i = 0; i < RBAT; ++i) res[i].u = u32x2{0u, 0u};
+            }
+#pragma unroll
+            for (int ii = 0; ii < RBAT; ++ii) {
+              const int i = ib + ii;
+              float v[4] = {acc[i][NB - 1][0], acc[i][NB - 1][1], acc[i][NB - 1][2], acc[i][NB - 1][3]};
+              if (rb_row) {
+                const float4 b = *(const float4*)(p.rowbias + ((int64_t)(mrow + i * 16) / p.rows_per_group) * p.ld_rowbias + n);
+                v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+              }
+              if (has_res) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)res[ii].e[e];
+              }
+              char* op = outb + (size_t)(i * 16) * ldo_b + on;
+              if (p.out_f32) {
+                *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
+              } else {
+                H4 t;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) t.e[e] = (f16)v[e];
+                *(u32x2*)op = t.u;
+              }
+            }
+          }
+        }
+      }
     }
-    if (SCHED != 3 && grp == 0) __builtin_amdgcn_s_barrier();
+    if (!has_next) break;
+    vb = vbn;
+    m0 = m0n;
+    n0 = n0n;
+  }
+  if constexpr (PHASED && SCHED >= 1) {
     if (TIMED && p.workspace != nullptr && blockIdx.x == gridDim.x / 2 && (wave & 3) == 0 && lane == 0) {
       uint32_t* o = (uint32_t*)p.workspace + grp * 32;
 #pragma unroll
       for (int q = 0; q < 20; ++q) o[q] = tacc[q];
       o[20] = (uint32_t)nk;
     }
+  }
 #undef ANIP_G2_STAMP
 #undef ANIP_G2_DMA_A
 #undef ANIP_G2_DMA_B
@@ -601,441 +1093,21 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
 #undef ANIP_G2_BAR_L
 #undef ANIP_G2_BAR_C
 #undef ANIP_G2_MMA
-  } else if (PHASED) {
-    // Role-alternating schedule for the one-block-per-CU wide tiles.  A K-tile is two 32-deep steps; every step is a
-    // LOAD segment (all ds_reads of the step's fragments, plus the DMA issue of the next K-tile on the first step)
-    // and a COMPUTE segment (FM x NB MFMAs on registers only), each closed by an s_barrier.  Waves 4-7 run one
-    // barrier behind waves 0-3 (they execute one extra barrier up front, waves 0-3 one at the end), so on every SIMD
-    // — waves w and w+4 share one — a wave's COMPUTE segment always coincides with its partner's LOAD segment: the
-    // matrix pipe never waits for LDS or for the barrier.
-    //   barrier numbering: group 0 passes #2s after LOAD(s) and #2s+1 after COMPUTE(s); group 1 passes #2s+1 after
-    //   LOAD(s) and #2s+2 after COMPUTE(s).  K-tile t+1 is issued in LOAD(2t) (its stage was last read in LOAD(2t-1),
-    //   complete before #4t-1) and every wave drains its DMA before #4t+3, after which the first reads of tile t+1 follow.
-    const int grp = wave >> 2;
-    if (nk > 0) issue(kt_begin, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();
-    for (int s2 = 0; s2 < 2 * nk; ++s2) {
-      const int t = s2 >> 1, kh = s2 & 1;
-      if (kh == 0 && t + 1 < nk) issue(kt_begin + t + 1, (t + 1) & 1);
-      const char* sa = smem + (t & 1) * STAGE;
-      const char* sb = sa + A_BYTES;
-      const int ko = kh ? koff[KH - 1] : koff[0];
-      f16x8 af[FM], bf[NB];
-#pragma unroll
-      for (int j = 0; j < NB; ++j) bf[j] = *(const f16x8*)(sb + (tile_c(j) + fr) * RB + ko);
-#pragma unroll
-      for (int i = 0; i < FM; ++i) af[i] = *(const f16x8*)(sa + a_row_off + i * 16 * RB + ko);
-      if (grp == 1 && kh == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-#ifdef ANIP_GEMM2_EXPERIMENTS
-      if (!(dbg & 4))
-#endif
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int j = 0; j < NB; ++j)
-            acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0)
-                              : __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-      if (grp == 0 && kh == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();
-  } else {
-#pragma unroll
-    for (int t = 0; t < NST - 1; ++t)
-      if (t < nk) issue(kt_begin + t, t);
-    for (int kt = 0; kt < nk; ++kt) {
-      // this wave's part of tile kt has landed; later tiles (if any were issued) stay in flight
-      if (NST > 2 && kt + 1 < nk) {
-        if (my_b == NB_I) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (NA_I + NB_I)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (NA_I + NB_I - 1)) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_s_barrier();  // tile kt is complete for all waves; the stage read at kt-1 is free
-      if (kt + NST - 1 < nk) issue(kt_begin + kt + NST - 1, (kt + NST - 1) % NST);
-      const char* sa = smem + (kt % NST) * STAGE;
-      const char* sb = sa + A_BYTES;
-#pragma unroll
-      for (int kh = 0; kh < KH; ++kh) {
-        f16x8 bf[NB];
-#pragma unroll
-        for (int t = 0; t < NB; ++t) bf[t] = *(const f16x8*)(sb + (tile_c(t) + fr) * RB + koff[kh]);
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-          const f16x8 af = *(const f16x8*)(sa + a_row_off + i * 16 * RB + koff[kh]);
-#ifdef ANIP_GEMM2_EXPERIMENTS
-          if (!(dbg & 4))      // experiment: no MFMAs
-#endif
-#pragma unroll
-            for (int j = 0; j < NB; ++j)
-              acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0)
-                                : __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af, acc[i][j], 0, 0, 0);
-        }
-      }
-    }
-  }
+}
 
-  // ---- epilogue: straight from the accumulators ------------------------------------------------------
-  //   !TRANS: acc[i][j][r] = C[m0 + wm*WTM + i*16 + fr][n0 + wn*WTN + j*16 + fq*4 + r]
-  //    TRANS: acc[i][j][r] = C[m0 + wm*WTM + i*16 + fq*4 + r][n0 + wn*WTN + j*16 + fr]
-  if (dbg & 1) {           // experiment: no epilogue (keep the accumulators live)
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-      for (int j = 0; j < NB; ++j) asm volatile("" ::"v"(acc[i][j]));
-    return;
+// ANIP_GEMM2_PERSIST: 1 = persistent walk for the quarter-phased wide tiles (see launch_gemm2), 0 = one workgroup per tile
+inline int gemm2_persistent() {
+  static const int v = getenv("ANIP_GEMM2_PERSIST") ? atoi(getenv("ANIP_GEMM2_PERSIST")) : 0;
+  return v;
+}
+inline int gemm2_cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : -1;
   }
-  const float alpha = p.alpha;
-  const int64_t obatch = (p.batch > 1) ? (int64_t)blockIdx.y * p.strideO : 0;
-  const int tsel = fq & 1, csel = (fq >> 1) * 8;   // after row_swap: tile of the pair / column offset in it
-
-  // 8 consecutive output columns [n, n+8) of row m: bias / row-group bias / residual / store
-  // (add_bias / add_rb: false when the accumulators were started from that term — acc_has_bias / rb_uni above)
-  auto emit8 = [&](int m, int n, int ncols, float (&v)[8], bool add_bias, bool add_rb, bool add_res) {
-    if (m >= p.M) return;
-    const int nvalid = min(8, ncols - n);
-    if (nvalid <= 0) return;
-    if (add_bias && p.bias != nullptr) {
-      if (nvalid == 8) {
-        const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 4);
-        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (e < nvalid) v[e] += p.bias[n + e];
-      }
-    }
-    if (add_rb && p.rowbias != nullptr) {
-      const float* rbp = p.rowbias + ((int64_t)m / p.rows_per_group) * p.ld_rowbias + n;
-      if (nvalid == 8 && ((p.ld_rowbias & 3) == 0) && (((uintptr_t)p.rowbias & 15) == 0)) {
-        const float4 b0 = *(const float4*)rbp, b1 = *(const float4*)(rbp + 4);
-        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-        v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (e < nvalid) v[e] += rbp[e];
-      }
-    }
-    if (add_res && p.residual != nullptr) {
-      const f16* rp = (const f16*)p.residual + (int64_t)m * p.ldr + n;
-      if (nvalid == 8 && ((p.ldr & 7) == 0)) {
-        U4H8 t;
-        t.u = *(const u32x4*)rp;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += (float)t.e[e];
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (e < nvalid) v[e] += (float)rp[e];
-      }
-    }
-    const int64_t o = p.head_dim > 0 ? ((int64_t)(n / p.head_dim) * p.M + m) * p.head_dim + n % p.head_dim
-                                     : obatch + (int64_t)m * p.ldo + n;
-    const int64_t ldo_eff = p.head_dim > 0 ? p.head_dim : p.ldo;
-    if (p.out_f32) {
-      float* op = (float*)p.out + o;
-      if (nvalid == 8 && ((p.ldo & 3) == 0)) {
-        *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
-        *(float4*)(op + 4) = make_float4(v[4], v[5], v[6], v[7]);
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (e < nvalid) op[e] = v[e];
-      }
-    } else {
-      f16* op = (f16*)p.out + o;
-      if (nvalid == 8 && ((ldo_eff & 7) == 0)) {
-        U4H8 t;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) t.e[e] = (f16)v[e];
-        *(u32x4*)op = t.u;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (e < nvalid) op[e] = (f16)v[e];
-      }
-    }
-  };
-  // 4 consecutive output columns (the unpaired last tile when BN/32 is odd)
-  auto emit4 = [&](int m, int n, float (&v)[4], bool add_bias, bool add_rb) {
-    if (m >= p.M) return;
-    const int nvalid = min(4, p.N - n);
-    if (nvalid <= 0) return;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (e < nvalid) {
-        if (add_bias && p.bias != nullptr) v[e] += p.bias[n + e];
-        if (add_rb && p.rowbias != nullptr) v[e] += p.rowbias[((int64_t)m / p.rows_per_group) * p.ld_rowbias + n + e];
-      }
-    }
-    if (p.residual != nullptr) {
-      const f16* rp = (const f16*)p.residual + (int64_t)m * p.ldr + n;
-      if (nvalid == 4 && ((p.ldr & 3) == 0)) {
-        union { u32x2 u; f16 e[4]; } t;
-        t.u = *(const u32x2*)rp;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)t.e[e];
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (e < nvalid) v[e] += (float)rp[e];
-      }
-    }
-    const int64_t o = p.head_dim > 0 ? ((int64_t)(n / p.head_dim) * p.M + m) * p.head_dim + n % p.head_dim
-                                     : obatch + (int64_t)m * p.ldo + n;
-    const int64_t ldo_eff = p.head_dim > 0 ? p.head_dim : p.ldo;
-    if (p.out_f32) {
-      float* op = (float*)p.out + o;
-      if (nvalid == 4 && ((p.ldo & 3) == 0)) *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
-      else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (e < nvalid) op[e] = v[e];
-      }
-    } else {
-      f16* op = (f16*)p.out + o;
-      if (nvalid == 4 && ((ldo_eff & 3) == 0)) {
-        union { u32x2 u; f16 e[4]; } t;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) t.e[e] = (f16)v[e];
-        *(u32x2*)op = t.u;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (e < nvalid) op[e] = (f16)v[e];
-      }
-    }
-  };
-
-  if (TRANS) {
-    // out[n][m], m contiguous: pair the tiles (i, i+1) along M; bias only (checked by the launcher)
-    float bt[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {       // all bias loads in front of the first store
-      const int n = n0 + tile_c(j) + fr;
-      bt[j] = (p.bias != nullptr && n < p.N) ? p.bias[n] : 0.f;
-    }
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      const int n = n0 + tile_c(j) + fr;
-      const float bn_ = bt[j];
-#pragma unroll
-      for (int ip = 0; ip < FM / 2; ++ip) {
-        float x[4], y[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          x[r] = acc[2 * ip][j][r] * alpha + bn_;
-          y[r] = acc[2 * ip + 1][j][r] * alpha + bn_;
-          row_swap(x[r], y[r]);
-        }
-        const int m = m0 + wm * WTM + (2 * ip + tsel) * 16 + csel;
-        if (n < p.N && m < p.M) {
-          f16* op = (f16*)p.out + obatch + (int64_t)n * p.ldo + m;
-          if (m + 8 <= p.M && ((p.ldo & 7) == 0)) {
-            U4H8 t;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { t.e[r] = (f16)x[r]; t.e[4 + r] = (f16)y[r]; }
-            *(u32x4*)op = t.u;
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              if (m + r < p.M) op[r] = (f16)x[r];
-              if (m + 4 + r < p.M) op[4 + r] = (f16)y[r];
-            }
-          }
-        }
-      }
-    }
-  } else if (p.act == 1) {
-    // GEGLU: packed columns per 32 = [16 x value | 16 x gate] -> tiles (2t, 2t+1) of a wave are the value / gate
-    // of the same 16 output columns; out column = packed column / 2
-    if (NB == 4) {
-      const int pn = n0 + wn * WTN + fq * 4;          // packed column of acc[i][0][0]
-      float bv0[4], bg0[4], bv1[4], bg1[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const bool hb = p.bias != nullptr && !acc_has_bias;
-        bv0[r] = (hb && pn + r < p.N) ? p.bias[pn + r] : 0.f;
-        bg0[r] = (hb && pn + 16 + r < p.N) ? p.bias[pn + 16 + r] : 0.f;
-        bv1[r] = (hb && pn + 32 + r < p.N) ? p.bias[pn + 32 + r] : 0.f;
-        bg1[r] = (hb && pn + 48 + r < p.N) ? p.bias[pn + 48 + r] : 0.f;
-      }
-      const int ocol = (n0 + wn * WTN) / 2 + tsel * 16 + csel;
-#pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        float v[8];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float h0 = (acc[i][0][r] * alpha + bv0[r]) * ANIP_GELU(acc[i][1][r] * alpha + bg0[r]);
-          float h1 = (acc[i][2][r] * alpha + bv1[r]) * ANIP_GELU(acc[i][3][r] * alpha + bg1[r]);
-          row_swap(h0, h1);
-          v[r] = h0;
-          v[4 + r] = h1;
-        }
-        emit8(m0 + wm * WTM + i * 16 + fr, ocol, p.N / 2, v, false, false, false);
-      }
-    }
-  } else {
-    // A block whose tile lies fully inside the output and whose operands allow 16-B accesses (every hot shape of the
-    // path) takes the tight epilogue below; ragged tiles take the general per-element-guarded one.
-    const bool has_rb = p.rowbias != nullptr, has_res = p.residual != nullptr;
-    // (32-bit per-lane byte offsets: the output / residual extents must stay below 4 GiB)
-    const bool tight = !(dbg & 8) && p.alpha == 1.0f && m0 + BM2 <= p.M && n0 + BN <= p.N &&
-                       (p.out_f32 ? (p.ldo & 3) == 0 : ((p.head_dim > 0 ? p.head_dim : p.ldo) & 7) == 0) &&
-                       (!has_res || (p.ldr & 7) == 0) &&
-                       (acc_has_bias || (p.bias == nullptr && !has_rb)) &&
-                       (int64_t)p.M * p.ldo * (p.out_f32 ? 4 : 2) < (1ll << 32) &&
-                       (!has_res || (int64_t)p.M * p.ldr * 2 < (1ll << 32));
-    if (!tight) {
-      // general path.  The accumulators may ALREADY hold the bias (and a block-uniform row-group bias): a full tile with
-      // 16-B accessible bias terms takes `acc_has_bias` whether or not the rest of the tight conditions hold (output of
-      // 4 GiB or more, unaligned leading dimensions).  Round 2 added them a second time here — the decoded frames of a
-      // 16-frame VAE batch at 512x512 / 768x768 (2^30+ output elements in the upsampler convs) carried every channel's
-      // bias twice: the "46 dB at 512x512, 38 dB at 768x768" of the round-2 / round-3 parity runs.
-      const bool add_bias = !acc_has_bias, add_rb = !(acc_has_bias && rb_uni);
-#pragma unroll
-      for (int jp = 0; jp < NB / 2; ++jp) {
-        const int n = n0 + tile_c(2 * jp) + tsel * 16 + csel;
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-          float v[8];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float x = acc[i][2 * jp][r] * alpha, y = acc[i][2 * jp + 1][r] * alpha;
-            row_swap(x, y);
-            v[r] = x;
-            v[4 + r] = y;
-          }
-          emit8(m0 + wm * WTM + i * 16 + fr, n, p.N, v, add_bias, add_rb, true);
-        }
-      }
-      if (NB & 1) {
-        const int n = n0 + tile_c(NB - 1) + fq * 4;
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = acc[i][NB - 1][r] * alpha;
-          emit4(m0 + wm * WTM + i * 16 + fr, n, v, add_bias, add_rb);
-        }
-      }
-    } else {
-      // Residual vectors in batches AHEAD of the stores.  `out` may alias anything as far as the compiler knows, so a
-      // load written after a store stays after it: fetched where they are used (the general path), every (row block,
-      // column pair) pays a dependent L2 / HBM round trip behind the previous stores — FM * NB/2 of them per wave with
-      // one KiB in flight each, which capped the K = 320 / 640 layers at ~2.5 TB/s.  Here RBAT residual vectors of a
-      // column pair are in flight together before the first of their stores; bias and block-uniform row-group bias
-      // are already inside the accumulators.  (RBAT: what the 128-VGPR budget of the 4-waves-per-SIMD tiles allows.)
-      constexpr int RBAT = (NW == 8 && WNW == 2 && NB == 5) ? 2 : FM;   // 256 x 160, 4 waves per SIMD: 128 VGPRs
-      // addressing: wave-uniform 64-bit bases (+ the uniform 16-row step) in SGPRs, one 32-bit per-lane BYTE offset —
-      // 64-bit per-lane pointers for every (row block, column pair) do not fit the 128-VGPR budget next to the
-      // accumulators
-      const int mrow = m0 + wm * WTM + fr;                 // row of acc[0][.]; tile i is 16 rows further down
-      const uint32_t esz = p.out_f32 ? 4u : 2u;
-      const bool hm = p.head_dim > 0;      // head-major output: row step = head_dim, plus a per-column head offset
-      const uint32_t ldr_b = (uint32_t)p.ldr * 2u, ldo_b = (uint32_t)(hm ? p.head_dim : p.ldo) * esz;
-      const char* resb = (const char*)p.residual;
-      char* outb = (char*)p.out + obatch * (int64_t)esz;
-      const uint32_t rrow = (uint32_t)mrow * ldr_b, orow = (uint32_t)mrow * ldo_b;
-      const bool rb_row = has_rb && !rb_uni;               // row-group bias that changes inside the block (rare)
-#pragma unroll
-      for (int jp = 0; jp < NB / 2; ++jp) {
-        const int n = n0 + tile_c(2 * jp) + tsel * 16 + csel;
-        const uint32_t rn = rrow + (uint32_t)n * 2u;
-        const uint32_t on = orow + (hm ? ((uint32_t)(n / p.head_dim) * (uint32_t)p.M * (uint32_t)p.head_dim +
-                                          (uint32_t)(n % p.head_dim)) : (uint32_t)n) * esz;
-#pragma unroll
-        for (int ib = 0; ib < FM; ib += RBAT) {
-          U4H8 res[RBAT];
-          if (has_res) {
-#pragma unroll
-            for (int i = 0; i < RBAT; ++i) res[i].u = *(const u32x4*)(resb + (size_t)((ib + i) * 16) * ldr_b + rn);
-          }
-#pragma unroll
-          for (int ii = 0; ii < RBAT; ++ii) {
-            const int i = ib + ii;
-            float v[8];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              float x = acc[i][2 * jp][r], y = acc[i][2 * jp + 1][r];
-              row_swap(x, y);
-              v[r] = x;
-              v[4 + r] = y;
-            }
-            if (rb_row) {
-              const float* rbp = p.rowbias + ((int64_t)(mrow + i * 16) / p.rows_per_group) * p.ld_rowbias + n;
-              const float4 b0 = *(const float4*)rbp, b1 = *(const float4*)(rbp + 4);
-              v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-              v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-            }
-            if (has_res) {
-#pragma unroll
-              for (int e = 0; e < 8; ++e) v[e] += (float)res[ii].e[e];
-            }
-            char* op = outb + (size_t)(i * 16) * ldo_b + on;
-            if (p.out_f32) {
-              *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
-              *(float4*)(op + 16) = make_float4(v[4], v[5], v[6], v[7]);
-            } else {
-              U4H8 t;
-#pragma unroll
-              for (int e = 0; e < 8; ++e) t.e[e] = (f16)v[e];
-              *(u32x4*)op = t.u;
-            }
-          }
-        }
-      }
-      if (NB & 1) {
-        const int n = n0 + tile_c(NB - 1) + fq * 4;
-        const uint32_t rn = rrow + (uint32_t)n * 2u;
-        const uint32_t on = orow + (hm ? ((uint32_t)(n / p.head_dim) * (uint32_t)p.M * (uint32_t)p.head_dim +
-                                          (uint32_t)(n % p.head_dim)) : (uint32_t)n) * esz;
-        union H4 { u32x2 u; f16 e[4]; };
-#pragma unroll
-        for (int ib = 0; ib < FM; ib += RBAT) {
-          H4 res[RBAT];
-          if (has_res) {
-#pragma unroll
-            for (int i = 0; i < RBAT; ++i) res[i].u = *(const u32x2*)(resb + (size_t)((ib + i) * 16) * ldr_b + rn);
-          }
-#pragma unroll
-          for (int ii = 0; ii < RBAT; ++ii) {
-            const int i = ib + ii;
-            float v[4] = {acc[i][NB - 1][0], acc[i][NB - 1][1], acc[i][NB - 1][2], acc[i][NB - 1][3]};
-            if (rb_row) {
-              const float4 b = *(const float4*)(p.rowbias + ((int64_t)(mrow + i * 16) / p.rows_per_group) * p.ld_rowbias + n);
-              v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-            }
-            if (has_res) {
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] += (float)res[ii].e[e];
-            }
-            char* op = outb + (size_t)(i * 16) * ldo_b + on;
-            if (p.out_f32) {
-              *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-              H4 t;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) t.e[e] = (f16)v[e];
-              *(u32x2*)op = t.u;
-            }
-          }
-        }
-      }
-    }
-  }
+  return n;
 }
 
 template <int BM2, int BN, int NW, int WNW, int BKT, int NST, bool CONV, bool TRANS, int SCHED = 0>
@@ -1053,7 +1125,15 @@ int launch_gemm2(const anip_gemm_params& p, hipStream_t stream, int splitk = 1) 
   }
   static const int dbg = getenv("ANIP_GEMM2_DBG") ? atoi(getenv("ANIP_GEMM2_DBG")) : 0;  // kernel experiments only
   const int nbm = (p.M + BM2 - 1) / BM2, nbn = (p.N + BN - 1) / BN;
-  hipLaunchKernelGGL((gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS, SCHED>), dim3((unsigned)(nbm * nbn), (unsigned)p.batch, 1),
+  unsigned grid = (unsigned)(nbm * nbn);
+  // Persistent form of the quarter-phased wide tiles (one workgroup per CU: 147 KB of LDS): a launch with more tiles than
+  // CUs starts one workgroup per CU, and each walks tiles blockIdx.x, + gridDim.x, ... with the first K-tile of the next
+  // tile staged under the epilogue of the running one (see the tile loop in the kernel).
+  if (SCHED == 1 && NST == 2 && gemm2_persistent() && p.batch <= 1 && splitk <= 1 && (p.K + BKT - 1) / BKT >= 2) {
+    const unsigned ncu = (unsigned)gemm2_cu_count();
+    if (ncu >= 8 && (ncu & 7) == 0 && grid > ncu) grid = ncu;
+  }
+  hipLaunchKernelGGL((gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS, SCHED>), dim3(grid, (unsigned)p.batch, 1),
                      dim3(NT2), LDS, stream, p, dbg, splitk);
   return 1;
 }
@@ -1172,8 +1252,9 @@ static int gemm2_split(const anip_gemm_params& p, int* cfg) {
   const int64_t tiles = (int64_t)((p.M + 127) / 128) * ((p.N + bn - 1) / bn);
   if (tiles * 2 < 128 || tiles >= 320) return 1;
   const int nk = (p.K + 31) / 32;
+  static const int mink = getenv("ANIP_GEMM2_SPLIT_MINK") ? max(1, atoi(getenv("ANIP_GEMM2_SPLIT_MINK"))) : 16;   // experiments
   int S = (int)min((int64_t)8, (512 + tiles - 1) / tiles);
-  S = min(S, nk / 16);                       // slices at least 512 deep
+  S = min(S, nk / mink);                     // slices at least 512 deep
   if (S < 2) return 1;
   const int per = (nk + S - 1) / S;
   return (nk + per - 1) / per;               // every slice non-empty
@@ -1244,7 +1325,8 @@ int anip_gemm2_try(const anip_gemm_params& p, hipStream_t stream) {
     if (p.act == 1) wbn = (pad256 * 100 <= (int64_t)p.N * 115) ? 256 : 0;   // GEGLU pairs tiles: even count per wave
     else if (pad320 <= pad256 && pad320 * 100 <= (int64_t)p.N * 115) wbn = 320;
     else if (pad256 * 100 <= (int64_t)p.N * 115) wbn = 256;
-    if (wbn != 0 && mt256 * ((p.N + wbn - 1) / wbn) * nb >= 192)          // >= 3/4 of the CUs busy
+    static const int wide_min = getenv("ANIP_GEMM2_WIDE_MIN") ? atoi(getenv("ANIP_GEMM2_WIDE_MIN")) : 192;   // experiments
+    if (wbn != 0 && mt256 * ((p.N + wbn - 1) / wbn) * nb >= wide_min)      // >= 3/4 of the CUs busy
       return wbn == 320 ? dispatch_gemm2<256, 320, 8, 4, 64, 2>(p, stream) : dispatch_gemm2<256, 256, 8, 4, 64, 2>(p, stream);
   }
   int bn = 128;

@@ -810,6 +810,64 @@ def test_gemm2_wide_conv3x3(N, H, W, Cin, Cout, stride, pad, pad_hi, up):
         close(out2, ref.cpu() + temb.cpu()[idx] + res.float().cpu(), "gemm2 wide conv3x3 + temb rowbias + residual")
 
 
+def test_gemm2_persistent_walk_shapes():
+    """more wide tiles than CUs (the persistent walk of launch_gemm2 when ANIP_GEMM2_PERSIST is on: a workgroup runs tiles
+    blockIdx.x, + gridDim.x, ... and stages the next tile's first K-tile in front of its epilogue): tile counts that are
+    not multiples of the CU count or of 8, every A loader, per-tile bias / row-group bias, residual; repeated runs must
+    be bit-identical (the walk keeps LDS-DMA in flight across the epilogue)."""
+    ops = _ops()
+    # two-source, bias + row-group bias + residual: 391 row tiles x 1
+    M, K1, K2, N = 100000, 320, 640, 320
+    A1 = rnd(M, K1, seed=401).to(DEV)
+    A2 = rnd(M, K2, seed=402).to(DEV)
+    W = rnd(N, K1 + K2, seed=403, scale=(K1 + K2) ** -0.5).to(DEV)
+    bias = rnd(N, seed=404).float().to(DEV)
+    rowbias = rnd(25, N, seed=405).float().to(DEV)
+    res = rnd(M, N, seed=406).to(DEV)
+    out = ops.gemm(A1, W, bias, A2=A2, rowbias=rowbias, rows_per_group=4096, residual=res)
+    ref = (_ref_mm_gpu(torch.cat([A1, A2], 1), W) + bias.cpu() + rowbias.cpu().repeat_interleave(4096, dim=0)[:M]
+           + res.float().cpu())
+    close(out, ref, "persistent walk: two-source + bias + rowbias + residual")
+    for _ in range(3):
+        assert torch.equal(ops.gemm(A1, W, bias, A2=A2, rowbias=rowbias, rows_per_group=4096, residual=res), out)
+    # three column tiles per row tile, K = 4 K-tiles (the shortest K the wide tiles are chosen for), ragged M
+    M, N, K = 90001, 960, 256
+    A = rnd(M, K, seed=407).to(DEV)
+    W = rnd(N, K, seed=408, scale=K ** -0.5).to(DEV)
+    bias = rnd(N, seed=409).float().to(DEV)
+    out = ops.gemm(A, W, bias)
+    close(out, _ref_mm_gpu(A, W) + bias.cpu(), "persistent walk: K = 256")
+    for _ in range(3):
+        assert torch.equal(ops.gemm(A, W, bias), out)
+    # 3x3 window loader, channel-block-major K, 512 tiles: bias + time-embedding row groups + residual
+    Nf, H, Wd, Cin, Cout = 32, 64, 64, 128, 320
+    x = rnd(Nf, H, Wd, Cin, seed=410).to(DEV)
+    w = rnd(Cout, Cin, 3, 3, seed=411, scale=(9 * Cin) ** -0.5)
+    b = rnd(Cout, seed=412).float().to(DEV)
+    wp = ops.pack_conv3x3(w).to(DEV)
+    temb = rnd(2, Cout, seed=413).float().to(DEV)
+    resc = rnd(Nf, H, Wd, Cout, seed=414).to(DEV)
+    out = ops.conv3x3(x, wp, b, rowbias=temb, rows_per_group=16 * H * Wd, residual=resc)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().to(DEV), b, padding=1).permute(0, 2, 3, 1).cpu()
+    ref = ref + temb.cpu().repeat_interleave(16, dim=0)[:, None, None, :] + resc.float().cpu()
+    close(out, ref, "persistent walk: conv3x3 + rowbias + residual")
+    for _ in range(3):
+        assert torch.equal(ops.conv3x3(x, wp, b, rowbias=temb, rows_per_group=16 * H * Wd, residual=resc), out)
+    # fused nearest-2x upsample loader, 512 tiles
+    xu = rnd(Nf, 32, 32, Cin, seed=415).to(DEV)
+    out = ops.conv3x3(xu, wp, b, upsample=True)
+    ref = F.conv2d(F.interpolate(xu.float().permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest"), w.float().to(DEV), b,
+                   padding=1).permute(0, 2, 3, 1)
+    close(out, ref, "persistent walk: upsample conv3x3")
+    # transposed and head-major outputs, 2 x 313 tiles
+    M = 80000
+    At = rnd(M, 640, seed=416).to(DEV)
+    Wt = rnd(640, 640, seed=417, scale=640 ** -0.5).to(DEV)
+    base = _ref_mm_gpu(At, Wt)
+    close(ops.gemm(At, Wt, None, trans_out=True), base.t(), "persistent walk: transposed out")
+    close(ops.gemm(At, Wt, None, head_dim=80), base.reshape(M, 8, 80).permute(1, 0, 2), "persistent walk: head-major out")
+
+
 def test_gemm2_bias_is_added_once_on_the_general_epilogue_path():
     """full tiles start their accumulators from the bias; the general (non-"tight") epilogue must not add it again.
     Two ways into that combination: a leading dimension that rules out 16-B stores (N = 648 -> ldo % 8 != 0 ... here
