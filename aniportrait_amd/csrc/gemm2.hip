@@ -63,6 +63,16 @@ __device__ __forceinline__ void row_swap(float& x, float& y) {
   y = __uint_as_float(r[1]);
 }
 
+// lanes fr and fr ^ 8 of a 16-lane row trade values (v_mov_dpp row_ror:8; the bank mask selects which half is written):
+//   half_swap_hi(keep, give): lanes 0-7 of each row keep `keep`, lanes 8-15 receive `give` of the lane 8 below
+//   half_swap_lo(keep, give): lanes 8-15 keep `keep`, lanes 0-7 receive `give` of the lane 8 above
+__device__ __forceinline__ float half_swap_hi(float keep, float give) {
+  return __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(keep), __float_as_uint(give), 0x128, 0xF, 0xC, false));
+}
+__device__ __forceinline__ float half_swap_lo(float keep, float give) {
+  return __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(keep), __float_as_uint(give), 0x128, 0xF, 0x3, false));
+}
+
 // Tile configurations (BM2 x BN x BKT, NW waves arranged (NW/WNW) x WNW):
 //   256 x {128,160} x 32, 8 waves 4x2, 3-stage ring, 2 blocks/CU  — many short-K tiles
 //   128 x {128,160} x 32, 4 waves 2x2, 3-stage ring, up to 3 blocks/CU — small problems
@@ -970,6 +980,11 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
         // column pair are in flight together before the first of their stores; bias and block-uniform row-group bias
         // are already inside the accumulators.  (RBAT: what the 128-VGPR budget of the 4-waves-per-SIMD tiles allows.)
         constexpr int RBAT = (NW == 8 && WNW == 2 && NB == 5) ? 2 : FM;   // 256 x 160, 4 waves per SIMD: 128 VGPRs
+#ifdef ANIP_GEMM2_PAIR_EPILOGUE
+        constexpr bool QUAD = false;           // experiment builds: round 2's 64-B row segments
+#else
+        constexpr bool QUAD = (NB == 4 || NB == 5);
+#endif
         // addressing: wave-uniform 64-bit bases (+ the uniform 16-row step) in SGPRs, one 32-bit per-lane BYTE offset —
         // 64-bit per-lane pointers for every (row block, column pair) do not fit the 128-VGPR budget next to the
         // accumulators
@@ -981,52 +996,137 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
         char* outb = (char*)p.out + obatch * (int64_t)esz;
         const uint32_t rrow = (uint32_t)mrow * ldr_b, orow = (uint32_t)mrow * ldo_b;
         const bool rb_row = has_rb && !rb_uni;               // row-group bias that changes inside the block (rare)
+        // Full-line stores (round 3).  A wave's first four 16-column tiles are 64 consecutive columns = one 128-B line of
+        // fp16 per row, but after the pair swap a store instruction covers 16 rows x 64 B (4 lanes per row): half lines.
+        // Measured with the same block tiles and nothing but the stores (tools/exp_store_pattern.py, 268 MB): 4.8 TB/s with
+        // 64-B row segments, 6.9 TB/s with 128-B ones; with a residual read of the same shape 3.8 vs 5.1 TB/s.  So the two
+        // pairs of a 16-row block trade halves across lanes fr <-> fr ^ 8 (one v_mov_dpp row_ror:8 per dword, the bank mask
+        // doing the select): store A = rows 0-7 of the block, store B = rows 8-15, each lane 16 B, 8 lanes = 128 B per row.
+        //   lane (fr < 8):  A <- own pair 0 of row fr          B <- pair 0 of row fr + 8 (from lane fr + 8)
+        //   lane (fr >= 8): A <- pair 1 of row fr - 8 (lane fr - 8)   B <- own pair 1 of row fr
+        // so a lane's column is the same in A and B: pair (fr >> 3), and the residual is fetched in the same two shapes.
+        if constexpr (QUAD) {
+          constexpr int RBQ = (NW == 8 && WNW == 2 && NB == 5) ? 1 : (NB == 5 ? 2 : FM / 2);   // 16-row blocks per residual batch (2 vectors each)
+          const int r8 = fr & 7;
+          const int n = n0 + tile_c(0) + (fr >> 3) * 32 + tsel * 16 + csel;
+          const int mq = m0 + wm * WTM + r8;                                // row of store A of block 0; B: + 8
+          const uint32_t rn = (uint32_t)mq * ldr_b + (uint32_t)n * 2u;
+          const uint32_t on = (uint32_t)mq * ldo_b + (hm ? ((uint32_t)(n / p.head_dim) * (uint32_t)p.M * (uint32_t)p.head_dim +
+                                                           (uint32_t)(n % p.head_dim)) : (uint32_t)n) * esz;
 #pragma unroll
-        for (int jp = 0; jp < NB / 2; ++jp) {
-          const int n = n0 + tile_c(2 * jp) + tsel * 16 + csel;
-          const uint32_t rn = rrow + (uint32_t)n * 2u;
-          const uint32_t on = orow + (hm ? ((uint32_t)(n / p.head_dim) * (uint32_t)p.M * (uint32_t)p.head_dim +
-                                            (uint32_t)(n % p.head_dim)) : (uint32_t)n) * esz;
-#pragma unroll
-          for (int ib = 0; ib < FM; ib += RBAT) {
-            U4H8 res[RBAT];
+          for (int ib = 0; ib < FM; ib += RBQ) {
+            U4H8 resA[RBQ], resB[RBQ];
             if (has_res) {
 #pragma unroll
-              for (int i = 0; i < RBAT; ++i) res[i].u = *(const u32x4*)(resb + (size_t)((ib + i) * 16) * ldr_b + rn);
+              for (int i = 0; i < RBQ; ++i) {
+                resA[i].u = *(const u32x4*)(resb + (size_t)((ib + i) * 16) * ldr_b + rn);
+                resB[i].u = *(const u32x4*)(resb + (size_t)((ib + i) * 16 + 8) * ldr_b + rn);
+              }
             } else if (PHASED && SCHED >= 1) {   // (defined either way: an undefined value becomes loop-carried state of the tile loop)
 #pragma unroll
-              for (int i = 0; i < RBAT; ++i) res[i].u = u32x4{0u, 0u, 0u, 0u};
+              for (int i = 0; i < RBQ; ++i) {
+                resA[i].u = u32x4{0u, 0u, 0u, 0u};
+                resB[i].u = u32x4{0u, 0u, 0u, 0u};
+              }
             }
 #pragma unroll
-            for (int ii = 0; ii < RBAT; ++ii) {
+            for (int ii = 0; ii < RBQ; ++ii) {
               const int i = ib + ii;
-              float v[8];
+              float va[8], vb[8];
 #pragma unroll
               for (int r = 0; r < 4; ++r) {
-                float x = acc[i][2 * jp][r], y = acc[i][2 * jp + 1][r];
-                row_swap(x, y);
-                v[r] = x;
-                v[4 + r] = y;
+                float x0 = acc[i][0][r], x1 = acc[i][1][r], y0 = acc[i][2][r], y1 = acc[i][3][r];
+                row_swap(x0, x1);            // pair 0: 8 consecutive columns (x0 | x1) of row fr
+                row_swap(y0, y1);            // pair 1
+                va[r] = half_swap_hi(x0, y0);
+                va[4 + r] = half_swap_hi(x1, y1);
+                vb[r] = half_swap_lo(y0, x0);
+                vb[4 + r] = half_swap_lo(y1, x1);
               }
               if (rb_row) {
-                const float* rbp = p.rowbias + ((int64_t)(mrow + i * 16) / p.rows_per_group) * p.ld_rowbias + n;
-                const float4 b0 = *(const float4*)rbp, b1 = *(const float4*)(rbp + 4);
-                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-                v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                const float* ra = p.rowbias + ((int64_t)(mq + i * 16) / p.rows_per_group) * p.ld_rowbias + n;
+                const float* rb_ = p.rowbias + ((int64_t)(mq + i * 16 + 8) / p.rows_per_group) * p.ld_rowbias + n;
+                const float4 a0 = *(const float4*)ra, a1 = *(const float4*)(ra + 4);
+                const float4 b0 = *(const float4*)rb_, b1 = *(const float4*)(rb_ + 4);
+                va[0] += a0.x; va[1] += a0.y; va[2] += a0.z; va[3] += a0.w;
+                va[4] += a1.x; va[5] += a1.y; va[6] += a1.z; va[7] += a1.w;
+                vb[0] += b0.x; vb[1] += b0.y; vb[2] += b0.z; vb[3] += b0.w;
+                vb[4] += b1.x; vb[5] += b1.y; vb[6] += b1.z; vb[7] += b1.w;
               }
               if (has_res) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)res[ii].e[e];
+                for (int e = 0; e < 8; ++e) {
+                  va[e] += (float)resA[ii].e[e];
+                  vb[e] += (float)resB[ii].e[e];
+                }
               }
-              char* op = outb + (size_t)(i * 16) * ldo_b + on;
+              char* opa = outb + (size_t)(i * 16) * ldo_b + on;
+              char* opb = outb + (size_t)(i * 16 + 8) * ldo_b + on;
               if (p.out_f32) {
-                *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
-                *(float4*)(op + 16) = make_float4(v[4], v[5], v[6], v[7]);
+                *(float4*)opa = make_float4(va[0], va[1], va[2], va[3]);
+                *(float4*)(opa + 16) = make_float4(va[4], va[5], va[6], va[7]);
+                *(float4*)opb = make_float4(vb[0], vb[1], vb[2], vb[3]);
+                *(float4*)(opb + 16) = make_float4(vb[4], vb[5], vb[6], vb[7]);
               } else {
-                U4H8 t;
+                U4H8 ta, tb;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) t.e[e] = (f16)v[e];
-                *(u32x4*)op = t.u;
+                for (int e = 0; e < 8; ++e) {
+                  ta.e[e] = (f16)va[e];
+                  tb.e[e] = (f16)vb[e];
+                }
+                *(u32x4*)opa = ta.u;
+                *(u32x4*)opb = tb.u;
+              }
+            }
+          }
+        } else {
+#pragma unroll
+          for (int jp = 0; jp < NB / 2; ++jp) {
+            const int n = n0 + tile_c(2 * jp) + tsel * 16 + csel;
+            const uint32_t rn = rrow + (uint32_t)n * 2u;
+            const uint32_t on = orow + (hm ? ((uint32_t)(n / p.head_dim) * (uint32_t)p.M * (uint32_t)p.head_dim +
+                                              (uint32_t)(n % p.head_dim)) : (uint32_t)n) * esz;
+#pragma unroll
+            for (int ib = 0; ib < FM; ib += RBAT) {
+              U4H8 res[RBAT];
+              if (has_res) {
+#pragma unroll
+                for (int i = 0; i < RBAT; ++i) res[i].u = *(const u32x4*)(resb + (size_t)((ib + i) * 16) * ldr_b + rn);
+              } else if (PHASED && SCHED >= 1) {   // (defined either way: an undefined value becomes loop-carried state of the tile loop)
+#pragma unroll
+                for (int i = 0; i < RBAT; ++i) res[i].u = u32x4{0u, 0u, 0u, 0u};
+              }
+#pragma unroll
+              for (int ii = 0; ii < RBAT; ++ii) {
+                const int i = ib + ii;
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                  float x = acc[i][2 * jp][r], y = acc[i][2 * jp + 1][r];
+                  row_swap(x, y);
+                  v[r] = x;
+                  v[4 + r] = y;
+                }
+                if (rb_row) {
+                  const float* rbp = p.rowbias + ((int64_t)(mrow + i * 16) / p.rows_per_group) * p.ld_rowbias + n;
+                  const float4 b0 = *(const float4*)rbp, b1 = *(const float4*)(rbp + 4);
+                  v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+                  v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                }
+                if (has_res) {
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) v[e] += (float)res[ii].e[e];
+                }
+                char* op = outb + (size_t)(i * 16) * ldo_b + on;
+                if (p.out_f32) {
+                  *(float4*)op = make_float4(v[0], v[1], v[2], v[3]);
+                  *(float4*)(op + 16) = make_float4(v[4], v[5], v[6], v[7]);
+                } else {
+                  U4H8 t;
+#pragma unroll
+                  for (int e = 0; e < 8; ++e) t.e[e] = (f16)v[e];
+                  *(u32x4*)op = t.u;
+                }
               }
             }
           }
@@ -1095,9 +1195,10 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
 #undef ANIP_G2_MMA
 }
 
-// ANIP_GEMM2_PERSIST: 1 = persistent walk for the quarter-phased wide tiles (see launch_gemm2), 0 = one workgroup per tile
+// ANIP_GEMM2_PERSIST: 1 (default) = persistent walk for the quarter-phased wide tiles (see launch_gemm2), 0 = one workgroup
+// per tile
 inline int gemm2_persistent() {
-  static const int v = getenv("ANIP_GEMM2_PERSIST") ? atoi(getenv("ANIP_GEMM2_PERSIST")) : 0;
+  static const int v = getenv("ANIP_GEMM2_PERSIST") ? atoi(getenv("ANIP_GEMM2_PERSIST")) : 1;
   return v;
 }
 inline int gemm2_cu_count() {
@@ -1227,7 +1328,10 @@ static int gemm2_split(const anip_gemm_params& p, int* cfg) {
   if (p.batch > 1 || p.act == 1 || p.trans_out || p.M < 1024 || p.M > 16384 || (p.N & 3) != 0) return 1;
   if (p.conv ? (p.Cin % 32 != 0) : (p.A2 != nullptr && (p.K1 % 32) != 0)) return 1;
   if ((((uintptr_t)p.bias | (uintptr_t)p.rowbias) & 15) != 0) return 1;
-  if (p.M > 4096) {
+  static const int wsplit_min_m = getenv("ANIP_GEMM2_WSPLIT_MINM") ? atoi(getenv("ANIP_GEMM2_WSPLIT_MINM")) : 4097;   // experiments
+  static const int wsplit_max_s = getenv("ANIP_GEMM2_WSPLIT_MAXS") ? atoi(getenv("ANIP_GEMM2_WSPLIT_MAXS")) : 4;
+  static const int wsplit_conv_only = getenv("ANIP_GEMM2_WSPLIT_CONV") ? atoi(getenv("ANIP_GEMM2_WSPLIT_CONV")) : 0;
+  if (p.M >= wsplit_min_m && (p.M > 4096 || !wsplit_conv_only || p.conv)) {
     // mid-size M (the 16x16 level): 2..4 slices of the wide tiles when those alone leave half the CUs idle
     const bool k64 = p.conv ? (p.Cin % 64 == 0) : (p.A2 == nullptr || p.K1 % 64 == 0);
     if (!k64 || p.K < 4096) return 1;
@@ -1239,7 +1343,7 @@ static int gemm2_split(const anip_gemm_params& p, int* cfg) {
     const int64_t tiles = (int64_t)((p.M + 255) / 256) * ((p.N + wbn - 1) / wbn);
     if (tiles >= 192) return 1;
     const int nk = (p.K + 63) / 64;
-    int S = (int)min((int64_t)4, (256 + tiles - 1) / tiles);
+    int S = (int)min((int64_t)wsplit_max_s, (256 + tiles - 1) / tiles);
     S = min(S, nk / 16);                     // slices at least 1024 deep
     if (S < 2) return 1;
     *cfg = wbn;
