@@ -1328,11 +1328,14 @@ static int gemm2_split(const anip_gemm_params& p, int* cfg) {
   if (p.batch > 1 || p.act == 1 || p.trans_out || p.M < 1024 || p.M > 16384 || (p.N & 3) != 0) return 1;
   if (p.conv ? (p.Cin % 32 != 0) : (p.A2 != nullptr && (p.K1 % 32) != 0)) return 1;
   if ((((uintptr_t)p.bias | (uintptr_t)p.rowbias) & 15) != 0) return 1;
-  static const int wsplit_min_m = getenv("ANIP_GEMM2_WSPLIT_MINM") ? atoi(getenv("ANIP_GEMM2_WSPLIT_MINM")) : 4097;   // experiments
-  static const int wsplit_max_s = getenv("ANIP_GEMM2_WSPLIT_MAXS") ? atoi(getenv("ANIP_GEMM2_WSPLIT_MAXS")) : 4;
-  static const int wsplit_conv_only = getenv("ANIP_GEMM2_WSPLIT_CONV") ? atoi(getenv("ANIP_GEMM2_WSPLIT_CONV")) : 0;
-  if (p.M >= wsplit_min_m && (p.M > 4096 || !wsplit_conv_only || p.conv)) {
-    // mid-size M (the 16x16 level): 2..4 slices of the wide tiles when those alone leave half the CUs idle
+  // experiment knobs: smallest M that takes the wide-tile split (default 2048: the 8x8 level), most slices (default 8)
+  static const int wsplit_min_m = getenv("ANIP_GEMM2_WSPLIT_MINM") ? atoi(getenv("ANIP_GEMM2_WSPLIT_MINM")) : 2048;
+  static const int wsplit_max_s = getenv("ANIP_GEMM2_WSPLIT_MAXS") ? atoi(getenv("ANIP_GEMM2_WSPLIT_MAXS")) : 8;
+  if (p.M >= wsplit_min_m) {
+    // M >= 2048 (the 8x8 and 16x16 levels): 2..8 slices of the WIDE tiles when K is long (3x3 convs, ff-out: K >= 4096) and
+    // the tiles alone leave half the CUs idle; shorter K: no split at all.  (Round 3, one call, same box: the 8x8 convs on
+    // 4 slices of 128 x 160 tiles 105 / 179 us, on 8 slices of 256 x 320 tiles 88 / 131 us — half the weight re-reads per
+    // row tile; M = 2048, N = K = 1280 on 2 slices + reduce 30.1 us, unsplit 25.6 us.)
     const bool k64 = p.conv ? (p.Cin % 64 == 0) : (p.A2 == nullptr || p.K1 % 64 == 0);
     if (!k64 || p.K < 4096) return 1;
     const int64_t pad320 = (int64_t)((p.N + 319) / 320) * 320, pad256 = (int64_t)((p.N + 255) / 256) * 256;

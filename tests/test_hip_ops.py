@@ -685,16 +685,24 @@ def test_gemm_split_k(M, N, K):
     close(out32, 0.5 * _ref_mm(A, W), f"gemm split-K f32 {M}x{N}x{K}", rtol=1e-3, arms=1e-3)
 
 
-def test_conv3x3_split_k():
+@pytest.mark.parametrize("Cin", [1280, 2560])
+def test_conv3x3_split_k(Cin):
+    """the 8x8 level: 32 wide tiles -> up to 8 K-slices of 256 x 320 tiles (round 3), bias + time-embedding rows + residual
+    applied by the reduce pass"""
     ops = _ops()
-    N_, H, Cin, Cout = 32, 8, 1280, 1280
+    N_, H, Cout = 32, 8, 1280
     x = rnd(N_, H, H, Cin, seed=125).to(DEV)
     w = rnd(Cout, Cin, 3, 3, seed=126, scale=(9 * Cin) ** -0.5)
     b = rnd(Cout, seed=127).float()
     res = rnd(N_, H, H, Cout, seed=128).to(DEV)
-    y = ops.conv3x3(x, ops.pack_conv3x3(w.to(DEV)), b.to(DEV), residual=res)
+    temb = rnd(2, Cout, seed=129).float()
+    y = ops.conv3x3(x, ops.pack_conv3x3(w.to(DEV)), b.to(DEV), rowbias=temb.to(DEV), rows_per_group=16 * H * H, residual=res)
     ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.float(), b, padding=1).permute(0, 2, 3, 1) + res.float().cpu()
-    close(y, ref, "conv3x3 split-K 8x8 1280")
+    ref = ref + temb.repeat_interleave(16, dim=0)[:, None, None, :]
+    close(y, ref, f"conv3x3 split-K 8x8 {Cin}->1280")
+    for _ in range(3):
+        assert torch.equal(ops.conv3x3(x, ops.pack_conv3x3(w.to(DEV)), b.to(DEV), rowbias=temb.to(DEV), rows_per_group=16 * H * H,
+                                       residual=res), y)
 
 
 @pytest.mark.parametrize("M", [128, 4096, 5000])
