@@ -96,4 +96,14 @@ __device__ __forceinline__ float gelu_poly_f(float x) {
   return fmaf(hx, p * z, hx);                // 0.5 x (1 + erf(x / sqrt 2))
 }
 
+// lanes fr and fr ^ 8 of a 16-lane row trade values (v_mov_dpp row_ror:8; the bank mask selects which half is written):
+//   half_swap_hi(keep, give): lanes 0-7 of each row keep `keep`, lanes 8-15 receive `give` of the lane 8 below
+//   half_swap_lo(keep, give): lanes 8-15 keep `keep`, lanes 0-7 receive `give` of the lane 8 above
+__device__ __forceinline__ float half_swap_hi(float keep, float give) {
+  return __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(keep), __float_as_uint(give), 0x128, 0xF, 0xC, false));
+}
+__device__ __forceinline__ float half_swap_lo(float keep, float give) {
+  return __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(keep), __float_as_uint(give), 0x128, 0xF, 0x3, false));
+}
+
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -206,10 +206,13 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs a) {
   const int tsel = fq & 1, csel = (fq >> 1) * 8;
   // residual vectors of a column pair in flight together AHEAD of its stores (a load written after a store stays after
   // it: `out` may alias anything as far as the compiler knows — see gemm2.hip)
-#pragma unroll
-  for (int jp = 0; jp < FN / 2; ++jp) {
-    const int n = tile_c(2 * jp) + tsel * 16 + csel;
-    U4H8 res[4];
+  // Full 128-B lines (round 3, as in gemm2.hip's tight epilogue): the wave's first four tiles are 64 consecutive columns; the
+  // two column pairs of a 16-row block trade halves across lanes fr <-> fr ^ 8, so that store A covers rows 0-7 and store
+  // B rows 8-15 of the block with 8 lanes x 16 B per row (64-B row segments: 4.8 TB/s, 128-B ones: 6.9 TB/s for the same
+  // bytes, tools/exp_store_pattern.py).  The residual is fetched in the same two shapes.
+  if constexpr (FN == 5 || FN == 4) {
+    const int r8 = fr & 7;
+    const int n = tile_c(0) + (fr >> 3) * 32 + tsel * 16 + csel;
     float add[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) add[e] = 0.f;
@@ -218,28 +221,74 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs a) {
       add[0] = b0.x; add[1] = b0.y; add[2] = b0.z; add[3] = b0.w;
       add[4] = b1.x; add[5] = b1.y; add[6] = b1.z; add[7] = b1.w;
     }
+    U4H8 resA[4], resB[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int m = m0 + wm * 64 + i * 16 + fr;
-      res[i].u = u32x4{0u, 0u, 0u, 0u};
-      if (a.res != nullptr && m < a.M) res[i].u = *(const u32x4*)(a.res + (int64_t)m * C_ + n);
+      const int ma = m0 + wm * 64 + i * 16 + r8;
+      resA[i].u = u32x4{0u, 0u, 0u, 0u};
+      resB[i].u = u32x4{0u, 0u, 0u, 0u};
+      if (a.res != nullptr && ma < a.M) resA[i].u = *(const u32x4*)(a.res + (int64_t)ma * C_ + n);
+      if (a.res != nullptr && ma + 8 < a.M) resB[i].u = *(const u32x4*)(a.res + (int64_t)(ma + 8) * C_ + n);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int m = m0 + wm * 64 + i * 16 + fr;
-      float v[8];
+      const int ma = m0 + wm * 64 + i * 16 + r8;
+      float va[8], vb[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float x = oacc[i][2 * jp][r], y = oacc[i][2 * jp + 1][r];
-        ffn_row_swap(x, y);
-        v[r] = x;
-        v[4 + r] = y;
+        float x0 = oacc[i][0][r], x1 = oacc[i][1][r], y0 = oacc[i][2][r], y1 = oacc[i][3][r];
+        ffn_row_swap(x0, x1);
+        ffn_row_swap(y0, y1);
+        va[r] = half_swap_hi(x0, y0);
+        va[4 + r] = half_swap_hi(x1, y1);
+        vb[r] = half_swap_lo(y0, x0);
+        vb[4 + r] = half_swap_lo(y1, x1);
       }
-      if (m < a.M) {
-        U4H8 t;
+      U4H8 ta, tb;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) t.e[e] = (f16)((v[e] + add[e]) + (float)res[i].e[e]);
-        *(u32x4*)(a.out + (int64_t)m * C_ + n) = t.u;
+      for (int e = 0; e < 8; ++e) {
+        ta.e[e] = (f16)((va[e] + add[e]) + (float)resA[i].e[e]);
+        tb.e[e] = (f16)((vb[e] + add[e]) + (float)resB[i].e[e]);
+      }
+      if (ma < a.M) *(u32x4*)(a.out + (int64_t)ma * C_ + n) = ta.u;
+      if (ma + 8 < a.M) *(u32x4*)(a.out + (int64_t)(ma + 8) * C_ + n) = tb.u;
+    }
+  } else {
+#pragma unroll
+    for (int jp = 0; jp < FN / 2; ++jp) {
+      const int n = tile_c(2 * jp) + tsel * 16 + csel;
+      U4H8 res[4];
+      float add[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) add[e] = 0.f;
+      if (a.b2 != nullptr) {
+        const float4 b0 = *(const float4*)(a.b2 + n), b1 = *(const float4*)(a.b2 + n + 4);
+        add[0] = b0.x; add[1] = b0.y; add[2] = b0.z; add[3] = b0.w;
+        add[4] = b1.x; add[5] = b1.y; add[6] = b1.z; add[7] = b1.w;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + fr;
+        res[i].u = u32x4{0u, 0u, 0u, 0u};
+        if (a.res != nullptr && m < a.M) res[i].u = *(const u32x4*)(a.res + (int64_t)m * C_ + n);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + fr;
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = oacc[i][2 * jp][r], y = oacc[i][2 * jp + 1][r];
+          ffn_row_swap(x, y);
+          v[r] = x;
+          v[4 + r] = y;
+        }
+        if (m < a.M) {
+          U4H8 t;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) t.e[e] = (f16)((v[e] + add[e]) + (float)res[i].e[e]);
+          *(u32x4*)(a.out + (int64_t)m * C_ + n) = t.u;
+        }
       }
     }
   }

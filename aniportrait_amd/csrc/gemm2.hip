@@ -63,16 +63,6 @@ __device__ __forceinline__ void row_swap(float& x, float& y) {
   y = __uint_as_float(r[1]);
 }
 
-// lanes fr and fr ^ 8 of a 16-lane row trade values (v_mov_dpp row_ror:8; the bank mask selects which half is written):
-//   half_swap_hi(keep, give): lanes 0-7 of each row keep `keep`, lanes 8-15 receive `give` of the lane 8 below
-//   half_swap_lo(keep, give): lanes 8-15 keep `keep`, lanes 0-7 receive `give` of the lane 8 above
-__device__ __forceinline__ float half_swap_hi(float keep, float give) {
-  return __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(keep), __float_as_uint(give), 0x128, 0xF, 0xC, false));
-}
-__device__ __forceinline__ float half_swap_lo(float keep, float give) {
-  return __uint_as_float(__builtin_amdgcn_update_dpp(__float_as_uint(keep), __float_as_uint(give), 0x128, 0xF, 0x3, false));
-}
-
 // Tile configurations (BM2 x BN x BKT, NW waves arranged (NW/WNW) x WNW):
 //   256 x {128,160} x 32, 8 waves 4x2, 3-stage ring, 2 blocks/CU  — many short-K tiles
 //   128 x {128,160} x 32, 4 waves 2x2, 3-stage ring, up to 3 blocks/CU — small problems
@@ -308,6 +298,9 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
   // 4 lanes x 16 B) 32 B off the 64-B access granule — rocprofv3 WRITE_SIZE 1.5x the output bytes on the N = 960
   // layer, the residual reads likewise.  Instead each wave takes NB - 1 tiles from a 64-B aligned contiguous range and
   // its last (single) tile from the tail of the block tile.
+  // (BN = 160: every second block tile starts 64 B off a 128-B line.  Dealing the single tiles FIRST there — so that the
+  // four-tile groups of the epilogue's full-line stores start on a line — measured 10 % SLOWER on the N = K = 320 layers,
+  // profiles/r03: one deal for all tiles.)
   auto tile_c = [&](int j) -> int {
     if ((NB & 1) == 0) return wn * WTN + j * 16;
     return j < NB - 1 ? wn * (NB - 1) * 16 + j * 16 : WNW * (NB - 1) * 16 + wn * 16;
