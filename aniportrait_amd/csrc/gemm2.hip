@@ -1445,5 +1445,6 @@ int anip_gemm2_try(const anip_gemm_params& p, hipStream_t stream) {
   static const int small_bk64 = getenv("ANIP_GEMM2_SMALL_BK64") ? atoi(getenv("ANIP_GEMM2_SMALL_BK64")) : 1;
   const int64_t tiles128 = (int64_t)((p.M + 127) / 128) * ((p.N + bn - 1) / bn) * nb;
   if (small_bk64 && k64 && p.K >= 512 && tiles128 <= 256)
+    return bn == 128 ? dispatch_gemm2<128, 128, 4, 2, 64, 3>(p, stream) : dispatch_gemm2<128, 160, 4, 2, 64, 3>(p, stream);
   return bn == 128 ? dispatch_gemm2<128, 128, 4, 2, 32, 3>(p, stream) : dispatch_gemm2<128, 160, 4, 2, 32, 3>(p, stream);
 }
