@@ -1436,7 +1436,8 @@ int anip_gemm2_try(const anip_gemm_params& p, hipStream_t stream) {
   }
   const int64_t tiles256 = mt256 * ((p.N + bn - 1) / bn) * nb;
   if (tiles256 * 2 < 128) return 0;
-  const bool big = tiles256 >= 1024;   // >= 2 full rounds of 2 x 256 resident 256-row blocks
+  static const int big_min = getenv("ANIP_GEMM2_BIG_MIN") ? atoi(getenv("ANIP_GEMM2_BIG_MIN")) : 1024;   // experiments
+  const bool big = tiles256 >= big_min;   // >= 2 full rounds of 2 x 256 resident 256-row blocks
   if (big) return bn == 128 ? dispatch_gemm2<256, 128, 8, 2, 32, 3>(p, stream) : dispatch_gemm2<256, 160, 8, 2, 32, 3>(p, stream);
   // At most one 128-row tile per CU (the 8x8 level, M = 2048): 64-deep K-tiles — the same 3-stage ring then holds twice the K
   // in flight, and these launches are bound by the L2 round trip per K-tile, not by LDS space (96 / 108 KB: one block per
