@@ -147,6 +147,8 @@ PY
     find $OUT/pmc_step -name "*kernel_trace*" -delete 2>/dev/null
     python tools/pmc_summarize.py $OUT/pmc_step $OUT/pmc_step_summary.json --families --calls $OUT/pmc_calls.json 2>&1 | tail -n 2
     find $OUT/pmc_step -name "*counter_collection*" -size +6M -delete 2>/dev/null ;;
+  usepmc)     # make this call's PMC summary the one bench.py reads (the committed copy is refreshed from it afterwards)
+    cp $OUT/pmc_step_summary.json profiles/pmc_traffic_latest.json && echo "profiles/pmc_traffic_latest.json <- $OUT/pmc_step_summary.json" ;;
   *) echo "unknown step $STEP" ;;
   esac
 done
