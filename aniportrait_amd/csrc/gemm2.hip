@@ -23,6 +23,10 @@
 //    residual, fp32 out; the transposed-out variant (V^T projection) keeps the un-swapped operand order and
 //    pairs tiles along M instead.  Single rounding to fp16.
 //  * XCD-aware bijective tile order: each XCD's private L2 sees a contiguous run of tiles sharing A panels.
+//  * (round 3) wide 256 x {256,320} x 64 tiles with a quarter-phased, role-alternating main loop; launched as a
+//    PERSISTENT WALK when there are more tiles than CUs (the next tile's first K-tile is staged in front of the running
+//    tile's epilogue); tight-epilogue stores / residual loads in whole 128-B lines (a DPP half swap between the two
+//    column pairs of a wave); wide-tile split-K for the 8x8 / 16x16 levels; 64-deep K-tiles for one-tile-per-CU launches.
 #include <stdlib.h>
 
 #include "common.h"
@@ -458,27 +462,27 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
   // LOAD that precedes the barrier the readers pass before they read (RAW), and every re-staged region was last read
   // at least one barrier earlier (WAR: the tightest pair is A-lo, read last at j=3 of tile t-1, re-staged at j=2 of t).
   constexpr bool HALF_BAR = (SCHED == 3);
-#define ANIP_G2_BAR_RAW()                  \
-  __builtin_amdgcn_sched_barrier(0);     \
-  __builtin_amdgcn_s_barrier();          \
+#define ANIP_G2_BAR_RAW()            \
+  __builtin_amdgcn_sched_barrier(0); \
+  __builtin_amdgcn_s_barrier();      \
   __builtin_amdgcn_sched_barrier(0)
-#define ANIP_G2_BAR_L()                                  \
-  if (!HALF_BAR || grp == 1) { ANIP_G2_BAR_RAW(); }    \
+#define ANIP_G2_BAR_L()                             \
+  if (!HALF_BAR || grp == 1) { ANIP_G2_BAR_RAW(); } \
   else { __builtin_amdgcn_sched_barrier(0); }
-#define ANIP_G2_BAR_C()                                  \
-  if (!HALF_BAR || grp == 0) { ANIP_G2_BAR_RAW(); }    \
+#define ANIP_G2_BAR_C()                             \
+  if (!HALF_BAR || grp == 0) { ANIP_G2_BAR_RAW(); } \
   else { __builtin_amdgcn_sched_barrier(0); }
-#define ANIP_G2_MMA(I0)                                                                                   \
-  __builtin_amdgcn_s_setprio(1);                                                                        \
-  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < NB; ++j)          \
-      acc[(I0) + i][j] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[(I0) + i][j], 0, 0, 0) \
+#define ANIP_G2_MMA(I0)                                                                                           \
+  __builtin_amdgcn_s_setprio(1);                                                                                  \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < NB; ++j)                    \
+      acc[(I0) + i][j] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[(I0) + i][j], 0, 0, 0)  \
                                : __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[(I0) + i][j], 0, 0, 0); \
   __builtin_amdgcn_s_setprio(0)
-#define ANIP_G2_DMA_B(I)                                  \
-  if (CONV) fire_b(nst, I);                             \
+#define ANIP_G2_DMA_B(I)    \
+  if (CONV) fire_b(nst, I); \
   else issue_b1(kt_begin + t + 1, nst, I)
-#define ANIP_G2_DMA_A(I)                                  \
-  if (CONV) fire_a(nst, I);                             \
+#define ANIP_G2_DMA_A(I)    \
+  if (CONV) fire_a(nst, I); \
   else issue_a1(kt_begin + t + 1, nst, I)
   // SCHED == 2 (-DANIP_GEMM2_TIMING builds only): the same loop with s_memtime stamps around every segment and barrier;
   // waves 0 and 4 of the middle block write, per sub-step j, the summed cycles of [LOAD work, wait at the barrier
@@ -491,11 +495,11 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
     for (int q = 0; q < 20; ++q) tacc[q] = 0;
     tprev = __builtin_readcyclecounter();
   }
-#define ANIP_G2_STAMP(Q)                                    \
-  if (TIMED) {                                            \
-    const uint64_t now_ = __builtin_readcyclecounter();   \
-    tacc[Q] += (uint32_t)(now_ - tprev);                  \
-    tprev = now_;                                         \
+#define ANIP_G2_STAMP(Q)                                \
+  if (TIMED) {                                          \
+    const uint64_t now_ = __builtin_readcyclecounter(); \
+    tacc[Q] += (uint32_t)(now_ - tprev);                \
+    tprev = now_;                                       \
   }
   const int grp = wave >> 2;
   if constexpr (PHASED && SCHED >= 1) {
