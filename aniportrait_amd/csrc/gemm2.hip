@@ -1443,13 +1443,15 @@ int anip_gemm2_try(const anip_gemm_params& p, hipStream_t stream) {
   static const int big_min = getenv("ANIP_GEMM2_BIG_MIN") ? atoi(getenv("ANIP_GEMM2_BIG_MIN")) : 1024;   // experiments
   const bool big = tiles256 >= big_min;   // >= 2 full rounds of 2 x 256 resident 256-row blocks
   if (big) return bn == 128 ? dispatch_gemm2<256, 128, 8, 2, 32, 3>(p, stream) : dispatch_gemm2<256, 160, 8, 2, 32, 3>(p, stream);
-  // At most one 128-row tile per CU (the 8x8 level, M = 2048): 64-deep K-tiles — the same 3-stage ring then holds twice the K
-  // in flight, and these launches are bound by the L2 round trip per K-tile, not by LDS space (96 / 108 KB: one block per
-  // CU).  Round 3, one call: M = 2048, N = K = 1280 25.6 -> 22.1 us, the 2560 -> 1280 shortcut 42.2 -> 35.0 us; with 512 tiles
-  // (M = 8192, two to three blocks per CU on the 32-deep tiles) it loses: 50.6 -> 61.8 us.  ANIP_GEMM2_SMALL_BK64=0: never.
+  // At most one 128-row tile per CU (the 8x8 level, M = 2048): 64-deep K-tiles and EIGHT waves per tile (wave tile 32 x 64 /
+  // 32 x 80).  These launches are bound by what one wave per SIMD can do in order — issue its share of the LDS-DMA, read its
+  // fragments, run its MFMAs — not by LDS space (96 / 108 KB: one block per CU) and not by the ring depth (a 4-stage ring:
+  // no change).  Round 3, A/B inside one call each: M = 2048, N = K = 1280 25.6 us (4 waves, 32-deep) -> 22.1 (64-deep) ->
+  // 19.1 (8 waves); the 2560 -> 1280 shortcut 42.2 -> 35.0 -> 30.9 us.  With 512 tiles (M = 8192: two to three blocks per
+  // CU on the 32-deep tiles) the 64-deep tiles lose: 50.6 -> 61.8 us.  ANIP_GEMM2_SMALL_BK64=0: never.
   static const int small_bk64 = getenv("ANIP_GEMM2_SMALL_BK64") ? atoi(getenv("ANIP_GEMM2_SMALL_BK64")) : 1;
   const int64_t tiles128 = (int64_t)((p.M + 127) / 128) * ((p.N + bn - 1) / bn) * nb;
   if (small_bk64 && k64 && p.K >= 512 && tiles128 <= 256)
-    return bn == 128 ? dispatch_gemm2<128, 128, 4, 2, 64, 3>(p, stream) : dispatch_gemm2<128, 160, 4, 2, 64, 3>(p, stream);
+    return bn == 128 ? dispatch_gemm2<128, 128, 8, 2, 64, 3>(p, stream) : dispatch_gemm2<128, 160, 8, 2, 64, 3>(p, stream);
   return bn == 128 ? dispatch_gemm2<128, 128, 4, 2, 32, 3>(p, stream) : dispatch_gemm2<128, 160, 4, 2, 32, 3>(p, stream);
 }
