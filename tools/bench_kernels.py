@@ -13,10 +13,36 @@ from aniportrait_amd import hipops as ops  # noqa: E402
 DEV = "cuda"
 
 
+COLD = False          # --cold: evict the Infinity Cache / L2 before every timed launch
+_FLUSH = None
+
+
+def _flush():
+    """write 768 MB: more than the 256 MB Infinity Cache + 8 x 4 MB L2, so the next launch finds its operands in HBM —
+    the pessimistic end of what a kernel sees inside the pipeline (there, operands written one or two launches earlier are
+    partly still cached; the default warm loop is the optimistic end: e.g. the N = K = 320 residual layers run 57 us warm,
+    79 us in the pipeline)"""
+    global _FLUSH
+    if _FLUSH is None:
+        _FLUSH = torch.empty(768 << 20, dtype=torch.uint8, device=DEV)
+    _FLUSH.add_(1)
+
+
 def timeit(fn, iters=10, warmup=3):
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
+    if COLD:
+        tot = 0.0
+        for _ in range(iters):
+            _flush()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            fn()
+            e.record()
+            torch.cuda.synchronize()
+            tot += s.elapsed_time(e)
+        return tot / iters * 1e-3
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(iters):
@@ -98,17 +124,20 @@ def bench_temporal(B, F, T, heads, d, tag):
 
 
 def main():
-    """--only gemm,conv,attn,norm   restrict the families;   env switches of the library (read once per process) make
+    """--only gemm,conv,attn,norm   restrict the families;   --cold   cache-cold launches (see _flush);   env switches of the library (read once per process) make
     one invocation = one kernel variant: ANIP_GEMM2_DBG=8 (round-1 epilogue), ANIP_GEMM2_CFG=1|2 (never / always the
     wide tiles), ANIP_ATTN_QH=1|2 (query groups per wave)."""
     import os
+    global COLD
     only = None
     for a in sys.argv[1:]:
         if a.startswith("--only"):
             only = set(a.split("=", 1)[1].split(","))
+        if a == "--cold":
+            COLD = True
     want = lambda k: only is None or k in only  # noqa: E731
-    print(json.dumps(dict(device=ops.device_info(), env={k: v for k, v in os.environ.items() if k.startswith("ANIP_")})),
-          flush=True)
+    print(json.dumps(dict(device=ops.device_info(), cold=COLD,
+                          env={k: v for k, v in os.environ.items() if k.startswith("ANIP_")})), flush=True)
     NF = 32
     if want("gemm"):
         # the Linear / 1x1 layers of one UNet3D call at C2 (shape, epilogue) — launches per call in the tag

@@ -35,7 +35,7 @@ PY
     grep -E "^FAILED|passed|failed|rc=" $OUT/ntests.log | tail -n 8 ;;
   kbench:*)   # kbench:<name> — tools/bench_kernels.py gemm,conv under the current environment -> kbench_<name>.jsonl
     N=${STEP#kbench:}
-    timeout 400 python tools/bench_kernels.py --only=gemm,conv > $OUT/kbench_$N.jsonl 2>&1; echo "rc=$?" ;;
+    timeout 400 python tools/bench_kernels.py --only=gemm,conv $KBENCH_FLAGS > $OUT/kbench_$N.jsonl 2>&1; echo "rc=$?" ;;   # env:KBENCH_FLAGS=--cold
   kcmp:*)     # kcmp:<a>:<b>
     AB=${STEP#kcmp:}; A=${AB%%:*}; B=${AB##*:}
     python - <<PY
