@@ -1010,10 +1010,34 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
           const uint32_t rn = (uint32_t)mq * ldr_b + (uint32_t)n * 2u;
           const uint32_t on = (uint32_t)mq * ldo_b + (hm ? ((uint32_t)(n / p.head_dim) * (uint32_t)p.M * (uint32_t)p.head_dim +
                                                            (uint32_t)(n % p.head_dim)) : (uint32_t)n) * esz;
+          // Experiment (ANIP_GEMM2_DBG bit 6; the one-tile-per-workgroup forms): the wave's residual sub-tile — WTM rows x
+          // 128 B — is fetched by LDS-DMA into the wave's own slice of the operand ring the main loop has vacated, ALL of it
+          // in flight at once, instead of one 16-row block of register loads per HBM round trip (the 128-VGPR budget of the
+          // 256 x 160 tiles allows no more): cache-cold, the N = K = 320 residual layers spend 101 us against 57 us warm
+          // (profiles/r03/zj_*), most of the difference in those dependent round trips.
+          constexpr bool RES_LDS_OK = !PHASED && (NST * (BM2 + BN) * BKT * 2) / NW >= WTM * 128;
+          const bool res_lds = RES_LDS_OK && has_res && (dbg & 64) != 0;
+          const char* rl = smem + wave * (WTM * 128);
+          if (RES_LDS_OK && res_lds) {
+            __builtin_amdgcn_s_barrier();                       // every wave has finished reading the operand ring
+            auto rR = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, (uint32_t)((int64_t)p.M * p.ldr * 2), 0x00020000);
+            const uint32_t v0 = (uint32_t)(m0 + wm * WTM + (lane >> 3)) * ldr_b + (uint32_t)(n0 + tile_c(0) + (lane & 7) * 8) * 2u;
+#pragma unroll
+            for (int q = 0; q < WTM / 8; ++q)                   // 8 rows x 128 B per instruction, lane-linear in LDS
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rR, LDS_PTR(rl + q * 1024), 16, v0 + (uint32_t)(q * 8) * ldr_b, 0, 0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          const int rl_off = r8 * 128 + ((fr >> 3) * 4 + tsel * 2 + (fq >> 1)) * 16;   // this lane's 16 B of row r8 in the slice
 #pragma unroll
           for (int ib = 0; ib < FM; ib += RBQ) {
             U4H8 resA[RBQ], resB[RBQ];
-            if (has_res) {
+            if (RES_LDS_OK && res_lds) {
+#pragma unroll
+              for (int i = 0; i < RBQ; ++i) {
+                resA[i].u = *(const u32x4*)(rl + ((ib + i) * 16) * 128 + rl_off);
+                resB[i].u = *(const u32x4*)(rl + ((ib + i) * 16 + 8) * 128 + rl_off);
+              }
+            } else if (has_res) {
 #pragma unroll
               for (int i = 0; i < RBQ; ++i) {
                 resA[i].u = *(const u32x4*)(resb + (size_t)((ib + i) * 16) * ldr_b + rn);

@@ -878,6 +878,26 @@ def test_gemm2_persistent_walk_shapes():
     close(ops.gemm(At, Wt, None, head_dim=80), base.reshape(M, 8, 80).permute(1, 0, 2), "persistent walk: head-major out")
 
 
+def test_gemm_residual_256x160_tiles():
+    """the N = K = 320 residual layers of the 64x64 level (256 x 160 x 32 tiles, two workgroups per CU): bias + row-group
+    bias + residual through the full-line epilogue; run-to-run identical.  (Also the shape of the LDS-staged residual
+    experiment, ANIP_GEMM2_DBG=64.)"""
+    ops = _ops()
+    M, N, K = 131072, 320, 320
+    A = rnd(M, K, seed=501).to(DEV)
+    W = rnd(N, K, seed=502, scale=K ** -0.5).to(DEV)
+    bias = rnd(N, seed=503).float().to(DEV)
+    rowbias = rnd(32, N, seed=504).float().to(DEV)
+    res = rnd(M, N, seed=505).to(DEV)
+    out = ops.gemm(A, W, bias, rowbias=rowbias, rows_per_group=4096, residual=res)
+    ref = _ref_mm_gpu(A, W) + bias.cpu() + rowbias.cpu().repeat_interleave(4096, dim=0) + res.float().cpu()
+    close(out, ref, "gemm 256x160 tiles: bias + rowbias + residual")
+    for _ in range(3):
+        assert torch.equal(ops.gemm(A, W, bias, rowbias=rowbias, rows_per_group=4096, residual=res), out)
+    outh = ops.gemm(A, W, None, residual=None, head_dim=40)
+    close(outh, _ref_mm_gpu(A, W).reshape(M, 8, 40).permute(1, 0, 2), "gemm 256x160 tiles: head-major out")
+
+
 def test_gemm2_bias_is_added_once_on_the_general_epilogue_path():
     """full tiles start their accumulators from the bias; the general (non-"tight") epilogue must not add it again.
     Two ways into that combination: a leading dimension that rules out 16-B stores (N = 648 -> ldo % 8 != 0 ... here
