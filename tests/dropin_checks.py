@@ -20,7 +20,7 @@ def _paths(with_reference):
 
 def check_script_imports(script, last_line):
     """execute the reference script's own import block (e.g. scripts/pose2vid.py:1-30) with this repository first on
-    the path: the seven shimmed modules resolve to aniportrait_amd, everything else falls through to the reference"""
+    the path: the shimmed modules resolve to aniportrait_amd, everything else falls through to the reference"""
     _paths(True)
     from dropin_driver import install_stub_modules
     install_stub_modules()
@@ -36,9 +36,13 @@ def check_script_imports(script, last_line):
     for shim in ("src.models.pose_guider", "src.models.unet_2d_condition", "src.models.unet_3d",
                  "src.pipelines.pipeline_pose2vid_long"):
         assert os.path.abspath(sys.modules[shim].__file__).startswith(os.path.join(REPO, "src") + os.sep)
-    for name in ("get_fps", "read_frames", "save_videos_grid", "LMKExtractor", "FaceMeshVisualizer"):
+    for name in ("LMKExtractor", "FaceMeshVisualizer"):
         mod = sys.modules[ns[name].__module__]
         assert os.path.abspath(mod.__file__).startswith(os.path.join(REFERENCE, "src") + os.sep), (name, mod.__file__)
+    for name in ("get_fps", "read_frames", "save_videos_grid"):          # the output side is shimmed too
+        assert ns[name].__module__ == "aniportrait_amd.video_io", (name, ns[name].__module__)
+    from src.utils.util import crop_face                                 # not ours: falls through to the reference's module
+    assert os.path.abspath(sys.modules[crop_face.__module__].__file__).startswith(os.path.join(REFERENCE, "src") + os.sep)
     for name in ("init_frame_interpolation_model", "batch_images_interpolation_tool"):   # the `-acc` plumbing is shimmed too
         assert ns[name].__module__ == "aniportrait_amd.frame_interpolation", (name, ns[name].__module__)
     assert issubclass(ns["Pose2VideoPipeline"], diffusers.DiffusionPipeline)
@@ -119,6 +123,19 @@ def check_script_main(tmp, device, weight_dtype):
         ref = O.pose2vid(sd4, {"unet": C.unet3d_kwargs(True), "vae": C.SD_VAE_SMALL}, clip, i["ref_image"],
                          list(pose_list), i["ref_pose"], i["W"], i["H"], i["L"], i["steps"], i["cfg"], lat, long=True)
     p = psnr(video, ref)
+    # the script's tail (scripts/pose2vid.py:176-196): [reference image | poses | result] side by side through the shimmed
+    # src.utils.util.save_videos_grid (a .gif here: PyAV is not installed)
+    import numpy as np
+    from PIL import Image
+    from src.utils.util import save_videos_grid
+    assert save_videos_grid.__module__ == "aniportrait_amd.video_io"
+    to_t = lambda im: torch.from_numpy(np.asarray(im.resize((i["W"], i["H"])), dtype=np.float32) / 255).permute(2, 0, 1)  # noqa: E731
+    ref_t = to_t(i["ref_image"])[None, :, None].repeat(1, 1, video.shape[2], 1, 1)
+    pose_t = torch.stack([to_t(Image.fromarray(a)) for a in pose_list], 0).transpose(0, 1)[None]
+    out = os.path.join(tmp, "out", "clip.gif")
+    save_videos_grid(torch.cat([ref_t, pose_t[:, :, :video.shape[2]], video], dim=0), out, n_rows=3, fps=8)
+    gif = Image.open(out)
+    assert gif.n_frames == i["L"] and gif.size == (3 * (i["W"] + 2) + 2, i["H"] + 4), (gif.n_frames, gif.size)
     print(f"OK script_main device={device} dtype={weight_dtype} PSNR={p:.2f} dB")
     assert p >= 40.0, p
 
