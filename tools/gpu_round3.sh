@@ -9,6 +9,10 @@
 #   rocprof      rocprofv3 --kernel-trace --stats of the bench command
 #   pmc          HBM-traffic PMC passes over the eager denoising step, paired with the traced wrapper calls
 #   alltests     the whole -m gpu suite
+#   env:VAR=V    export VAR=V for the following steps (library switches, KBENCH_FLAGS=--cold, ANIP_LIB=<experiment build>)
+#   kbench:<n> / nbench:<n> / ktests:<n> / kcmp:<a>:<b>   micro-benchmarks and kernel tests under the current environment,
+#                A/B table of two kbench runs of this call
+#   usepmc       make this call's PMC summary the profiles/pmc_traffic_latest.json that the following bench step reads
 TAG=${1:-r03a}; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
