@@ -1,0 +1,36 @@
+"""Issue rates of the VALU / transcendental / MFMA instructions behind the kernel models of DESIGN.md
+(tools/exp_valu_rates.hip, compiled here with hipcc).  Usage on the GPU box: python tools/exp_valu_rates.py
+Prints, per instruction and waves per SIMD, the cycles per instruction per wave and per SIMD."""
+import ctypes
+import json
+import os
+import subprocess
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = "/tmp/exp_valu_rates.so"
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-shared", "-fPIC", "-o", SO,
+                       os.path.join(HERE, "exp_valu_rates.hip")])
+lib = ctypes.CDLL(SO)
+lib.exp_rate.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p] * 3
+
+OPS = {0: ("v_exp_f32", 8), 1: ("v_rcp_f32", 8), 2: ("v_fma_f32", 8), 3: ("v_pk_fma_f16", 8), 4: ("v_dot2_f32_f16", 8),
+       5: ("v_cvt_pkrtz_f16_f32", 8), 6: ("v_max3_f32", 8), 7: ("v_mov_b32_dpp row_ror:8", 8), 8: ("v_exp_f16", 8),
+       9: ("v_pk_mul_f32", 8), 10: ("v_mfma_f32_16x16x32_f16", 8), 11: ("v_mfma_f32_32x32x16_f16", 8),
+       12: ("softmax mix: 8 fma + 8 exp + 4 cvt_pk", 20)}
+ITERS = 2000
+CUS = torch.cuda.get_device_properties(0).multi_processor_count
+for op, (name, per_iter) in OPS.items():
+    row = {"instruction": name}
+    for w in (1, 2, 4):
+        threads = 256 * w
+        out = torch.empty(CUS * threads, dtype=torch.float32, device="cuda")
+        cyc = torch.zeros(CUS * threads // 64, dtype=torch.int64, device="cuda")
+        for _ in range(2):
+            rc = lib.exp_rate(op, CUS, threads, ITERS, out.data_ptr(), cyc.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            assert rc == 0, rc
+        torch.cuda.synchronize()
+        c = cyc.double().median().item() / (ITERS * per_iter)
+        row[f"{w}_waves_per_simd"] = {"cycles_per_instr_per_wave": round(c, 2), "cycles_per_instr_per_simd": round(c / w, 2)}
+    print(json.dumps(row), flush=True)

@@ -12,6 +12,7 @@
 #   env:VAR=V    export VAR=V for the following steps (library switches, KBENCH_FLAGS=--cold, ANIP_LIB=<experiment build>)
 #   kbench:<n> / nbench:<n> / ktests:<n> / kcmp:<a>:<b>   micro-benchmarks and kernel tests under the current environment,
 #                A/B table of two kbench runs of this call
+#   valurates / storepattern   instruction issue-rate and store-shape micro-benchmarks (tools/exp_valu_rates.py, exp_store_pattern.py)
 #   usepmc       make this call's PMC summary the profiles/pmc_traffic_latest.json that the following bench step reads
 TAG=${1:-r03a}; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
@@ -151,6 +152,10 @@ PY
     find $OUT/pmc_step -name "*kernel_trace*" -delete 2>/dev/null
     python tools/pmc_summarize.py $OUT/pmc_step $OUT/pmc_step_summary.json --families --calls $OUT/pmc_calls.json 2>&1 | tail -n 2
     find $OUT/pmc_step -name "*counter_collection*" -size +6M -delete 2>/dev/null ;;
+  valurates)  # issue rates of the VALU / transcendental / MFMA instructions the kernel models use (tools/exp_valu_rates.py)
+    timeout 120 python tools/exp_valu_rates.py > $OUT/valu_rates.jsonl 2>&1; echo "rc=$?"; cat $OUT/valu_rates.jsonl | tail -n 14 ;;
+  storepattern)
+    timeout 120 python tools/exp_store_pattern.py > $OUT/store_pattern.jsonl 2>&1; echo "rc=$?"; tail -n 8 $OUT/store_pattern.jsonl ;;
   usepmc)     # make this call's PMC summary the one bench.py reads (the committed copy is refreshed from it afterwards)
     cp $OUT/pmc_step_summary.json profiles/pmc_traffic_latest.json && echo "profiles/pmc_traffic_latest.json <- $OUT/pmc_step_summary.json" ;;
   *) echo "unknown step $STEP" ;;
