@@ -12,7 +12,7 @@
 #   env:VAR=V    export VAR=V for the following steps (library switches, KBENCH_FLAGS=--cold, ANIP_LIB=<experiment build>)
 #   kbench:<n> / nbench:<n> / ktests:<n> / kcmp:<a>:<b>   micro-benchmarks and kernel tests under the current environment,
 #                A/B table of two kbench runs of this call
-#   valurates / storepattern   instruction issue-rate and store-shape micro-benchmarks (tools/exp_valu_rates.py, exp_store_pattern.py)
+#   valurates / storepattern / ldsdma   instruction issue-rate, store-shape and LDS-DMA micro-benchmarks (tools/exp_*.py)
 #   usepmc       make this call's PMC summary the profiles/pmc_traffic_latest.json that the following bench step reads
 TAG=${1:-r03a}; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
@@ -154,6 +154,8 @@ PY
     find $OUT/pmc_step -name "*counter_collection*" -size +6M -delete 2>/dev/null ;;
   valurates)  # issue rates of the VALU / transcendental / MFMA instructions the kernel models use (tools/exp_valu_rates.py)
     timeout 120 python tools/exp_valu_rates.py > $OUT/valu_rates.jsonl 2>&1; echo "rc=$?"; cat $OUT/valu_rates.jsonl | tail -n 14 ;;
+  ldsdma)     # global -> LDS throughput of one CU vs access shape / queue depth (tools/exp_lds_dma.py)
+    timeout 200 python tools/exp_lds_dma.py > $OUT/lds_dma.jsonl 2>&1; echo "rc=$?"; tail -n 12 $OUT/lds_dma.jsonl ;;
   storepattern)
     timeout 120 python tools/exp_store_pattern.py > $OUT/store_pattern.jsonl 2>&1; echo "rc=$?"; tail -n 8 $OUT/store_pattern.jsonl ;;
   usepmc)     # make this call's PMC summary the one bench.py reads (the committed copy is refreshed from it afterwards)
