@@ -56,6 +56,8 @@ REAL_PIPE_CASES = {
     "c2_4step": (512, 512, 16, 4, 3.5, 2, tuple(range(16))),      # BASELINE configs[1] geometry, 4 of 25 DDIM steps
     "c5_1step": (768, 768, 16, 1, 3.5, 3, (0, 5, 10, 15)),        # BASELINE configs[4] geometry (96x96 latents)
     "l40_windows": (128, 128, 40, 3, 3.5, 4, (0, 11, 12, 23, 36, 39)),  # 4 windows / step incl. the wrap-around one
+    "c2_25step": (512, 512, 16, 25, 3.5, 2, tuple(range(16))),    # BASELINE configs[1] IN FULL: the schedule bench.py times
+    "c5_4step": (768, 768, 16, 4, 3.5, 3, (0, 5, 10, 15)),        # BASELINE configs[4] geometry, 4 of 25 DDIM steps
 }
 
 

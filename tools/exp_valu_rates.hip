@@ -64,6 +64,84 @@ __global__ __launch_bounds__(1024) void rate_kernel(float* out, unsigned long lo
       asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1" : "+v"(c[4]) : "v"(c[5]));
       asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1" : "+v"(c[6]) : "v"(c[7]));
     }
+    if (OP == 13) { CHAINS8("v_permlane32_swap_b32 %0, %0", c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]); }
+    if (OP == 14) { CHAINS8("v_permlane16_swap_b32 %0, %0", c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]); }
+    if (OP == 15) { CHAINS8("v_pk_fma_f32 %0, %0, %0, %0", *(double*)&c[0], *(double*)&c[2], *(double*)&c[4], *(double*)&c[6],
+                            *(double*)&c[0], *(double*)&c[2], *(double*)&c[4], *(double*)&c[6]); }
+    // same-wave overlap: independent VALU work written between independent MFMAs (cycles per ITERATION reported)
+    if (OP == 16) {   // 2 x 32x32x16 + 8 v_exp (4 behind each)
+      acc16[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8, a8, acc16[0], 0, 0, 0);
+      asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
+      acc16[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8, a8, acc16[1], 0, 0, 0);
+      asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3" : "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+    }
+    if (OP == 17) {   // 2 x 32x32x16 + 16 v_fma (8 behind each)
+      acc16[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8, a8, acc16[0], 0, 0, 0);
+      CHAINS8("v_fma_f32 %0, %0, %0, %0", c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
+      acc16[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8, a8, acc16[1], 0, 0, 0);
+      CHAINS8("v_fma_f32 %0, %0, %0, %0", c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
+    }
+    if (OP == 18) {   // 4 x 16x16x32 + 8 v_exp (2 behind each)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        acc4[k] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, a8, acc4[k], 0, 0, 0);
+        asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1" : "+v"(c[2 * k]), "+v"(c[2 * k + 1]));
+      }
+    }
+    if (OP == 19) {   // one attention unit's instruction multiset, MFMA and VALU interleaved 1 : ~5:
+                      // 6 x 32x32x16 + 12 x 16x16x32 with 32 fma + 32 exp + 16 cvt_pk + 16 max3 spread behind them
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        acc16[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8, a8, acc16[k & 1], 0, 0, 0);
+        CHAINS8("v_fma_f32 %0, %0, %0, %0", c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
+      }
+#pragma unroll
+      for (int k = 0; k < 12; ++k) {
+        acc4[k & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, a8, acc4[k & 3], 0, 0, 0);
+        if (k < 8) {
+          asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
+          asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1\n v_cvt_pkrtz_f16_f32 %2, %2, %3" : "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+          asm volatile("v_max3_f32 %0, %0, %1, %2\n v_max3_f32 %3, %3, %1, %2" : "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+        }
+      }
+    }
+    if (OP == 20) {   // the same VALU multiset alone (no MFMA)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { CHAINS8("v_fma_f32 %0, %0, %0, %0", c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]); }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
+        asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1\n v_cvt_pkrtz_f16_f32 %2, %2, %3" : "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+        asm volatile("v_max3_f32 %0, %0, %1, %2\n v_max3_f32 %3, %3, %1, %2" : "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+      }
+    }
+    if (OP == 22) {   // legacy K = 8 form: 8 x v_mfma_f32_32x32x8_f16 on 2 accumulators
+      typedef f16 f16x4_ __attribute__((ext_vector_type(4)));
+      const f16x4_ a4 = {(f16)1, (f16)2, (f16)3, (f16)4};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) acc16[k] = __builtin_amdgcn_mfma_f32_32x32x8f16(a4, a4, acc16[k], 0, 0, 0);
+    }
+    if (OP == 23) {   // legacy 16x16x16: 8 on 4 accumulators
+      typedef f16 f16x4_ __attribute__((ext_vector_type(4)));
+      const f16x4_ a4 = {(f16)1, (f16)2, (f16)3, (f16)4};
+#pragma unroll
+      for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc4[k] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4, a4, acc4[k], 0, 0, 0);
+    }
+    if (OP == 24) {   // serial chain: 8 DEPENDENT v_max3 (latency, not issue rate)
+      asm volatile("v_max3_f32 %0, %0, %1, %2\n v_max3_f32 %0, %0, %2, %3\n v_max3_f32 %0, %0, %3, %4\n v_max3_f32 %0, %0, %4, %5\n"
+                   "v_max3_f32 %0, %0, %5, %6\n v_max3_f32 %0, %0, %6, %7\n v_max3_f32 %0, %0, %7, %1\n v_max3_f32 %0, %0, %1, %3"
+                   : "+v"(c[0]) : "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]));
+    }
+    if (OP == 21) {   // the same MFMA multiset alone
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc16[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8, a8, acc16[k & 1], 0, 0, 0);
+#pragma unroll
+      for (int k = 0; k < 12; ++k) acc4[k & 3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8, a8, acc4[k & 3], 0, 0, 0);
+    }
   }
   const unsigned long long t1 = __builtin_readcyclecounter();
   float s = 0.f;
@@ -79,7 +157,7 @@ __global__ __launch_bounds__(1024) void rate_kernel(float* out, unsigned long lo
 extern "C" int exp_rate(int op, int blocks, int threads, int iters, float* out, unsigned long long* cyc, void* stream) {
   hipStream_t s = (hipStream_t)stream;
 #define L(N) case N: hipLaunchKernelGGL(rate_kernel<N>, dim3(blocks), dim3(threads), 0, s, out, cyc, iters); break;
-  switch (op) { L(0) L(1) L(2) L(3) L(4) L(5) L(6) L(7) L(8) L(9) L(10) L(11) L(12) default: return -1; }
+  switch (op) { L(0) L(1) L(2) L(3) L(4) L(5) L(6) L(7) L(8) L(9) L(10) L(11) L(12) L(13) L(14) L(15) L(16) L(17) L(18) L(19) L(20) L(21) L(22) L(23) L(24) default: return -1; }
 #undef L
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -18,7 +18,15 @@ lib.exp_rate.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p] * 3
 OPS = {0: ("v_exp_f32", 8), 1: ("v_rcp_f32", 8), 2: ("v_fma_f32", 8), 3: ("v_pk_fma_f16", 8), 4: ("v_dot2_f32_f16", 8),
        5: ("v_cvt_pkrtz_f16_f32", 8), 6: ("v_max3_f32", 8), 7: ("v_mov_b32_dpp row_ror:8", 8), 8: ("v_exp_f16", 8),
        9: ("v_pk_mul_f32", 8), 10: ("v_mfma_f32_16x16x32_f16", 8), 11: ("v_mfma_f32_32x32x16_f16", 8),
-       12: ("softmax mix: 8 fma + 8 exp + 4 cvt_pk", 20)}
+       12: ("softmax mix: 8 fma + 8 exp + 4 cvt_pk", 20), 13: ("v_permlane32_swap_b32", 8), 14: ("v_permlane16_swap_b32", 8),
+       15: ("v_pk_fma_f32", 8),
+       # same-wave MFMA / VALU overlap: cycles per ITERATION of the mix (per_iter = 1)
+       16: ("ITER: 2 mfma32x32x16 + 8 v_exp", 1), 17: ("ITER: 2 mfma32x32x16 + 16 v_fma", 1),
+       18: ("ITER: 4 mfma16x16x32 + 8 v_exp", 1),
+       19: ("ITER: attention unit mix (6 mfma32 + 12 mfma16 | 48 fma 32 exp 16 cvt 16 max3)", 1),
+       20: ("ITER: that VALU multiset alone", 1), 21: ("ITER: that MFMA multiset alone", 1),
+       22: ("v_mfma_f32_32x32x8_f16 (legacy K=8)", 8), 23: ("v_mfma_f32_16x16x16_f16 (legacy K=16)", 8),
+       24: ("v_max3_f32 DEPENDENT chain", 8)}
 ITERS = 2000
 CUS = torch.cuda.get_device_properties(0).multi_processor_count
 for op, (name, per_iter) in OPS.items():

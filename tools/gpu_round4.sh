@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-3 GPU session driver (one gpurun call = one invocation): `bash tools/gpu_round3.sh <tag> <step> [<step> ...]`,
+# round-4 GPU session driver (grown from tools/gpu_round4.sh) (one gpurun call = one invocation): `bash tools/gpu_round4.sh <tag> <step> [<step> ...]`,
 # steps run in the order given:
 #   parity       fixture-based real-width parity tests (C2 4 steps / C5 768 / L=40 windows)
 #   ktests<S>    kernel unit tests of the GEMM / conv family with ANIP_GEMM2_SCHED=<S> (0: round-2 loop, 1: quarter-phased)
@@ -152,8 +152,14 @@ PY
     find $OUT/pmc_step -name "*kernel_trace*" -delete 2>/dev/null
     python tools/pmc_summarize.py $OUT/pmc_step $OUT/pmc_step_summary.json --families --calls $OUT/pmc_calls.json 2>&1 | tail -n 2
     find $OUT/pmc_step -name "*counter_collection*" -size +6M -delete 2>/dev/null ;;
+  abench:*)   # abench:<name> — reference / temporal attention micro-benchmark under the current environment
+    N=${STEP#abench:}
+    timeout 300 python tools/bench_kernels.py --only=attn > $OUT/abench_$N.jsonl 2>&1; echo "rc=$?"; cat $OUT/abench_$N.jsonl | tail -n 12 ;;
+  atests)
+    timeout 600 python -m pytest tests/test_hip_ops.py -m gpu -q -k "attention or attn" > $OUT/atests.log 2>&1; echo "rc=$?" >> $OUT/atests.log
+    grep -E "^FAILED|^ERROR|passed|failed|rc=" $OUT/atests.log | tail -n 25 ;;
   valurates)  # issue rates of the VALU / transcendental / MFMA instructions the kernel models use (tools/exp_valu_rates.py)
-    timeout 120 python tools/exp_valu_rates.py > $OUT/valu_rates.jsonl 2>&1; echo "rc=$?"; cat $OUT/valu_rates.jsonl | tail -n 14 ;;
+    timeout 240 python tools/exp_valu_rates.py > $OUT/valu_rates.jsonl 2>&1; echo "rc=$?"; cat $OUT/valu_rates.jsonl | tail -n 30 ;;
   ldsdma)     # global -> LDS throughput of one CU vs access shape / queue depth (tools/exp_lds_dma.py)
     timeout 200 python tools/exp_lds_dma.py > $OUT/lds_dma.jsonl 2>&1; echo "rc=$?"; tail -n 12 $OUT/lds_dma.jsonl ;;
   storepattern)
