@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # ANIP_LIB: an experiment build of the same ABI (aniportrait_amd/build.py --out=...); the product is the default path
 LIB_PATH = os.environ.get("ANIP_LIB") or os.path.join(HERE, "lib", "libaniportrait_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -65,6 +65,9 @@ SIGNATURES = {
     "anip_ref_attention": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
                                    c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int,
                                    c_float, c_int64, c_int64, c_void_p]),
+    "anip_ref_attention_ex": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64,
+                                      c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int,
+                                      c_float, c_int64, c_int64, c_int, c_void_p]),
     "anip_temporal_attention": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "anip_softmax_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "anip_linear_small": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -13,27 +13,13 @@
 //    strided gather, one wave per problem, everything staged in LDS.
 #include <stdlib.h>
 
-#include "common.h"
+#include "attn_args.h"
 
 namespace {
 
 constexpr int NT = 256;
 constexpr int KV = 64;       // keys per tile
 constexpr int VROW = KV + 8; // fp16 elements per V^T LDS row (144 B = 9 x 16 B: odd -> conflict-free b128 reads)
-
-struct RefAttnArgs {
-  const f16* q; int64_t ldq;
-  const f16* k; int64_t ldk;
-  const f16* vt; int64_t ldvt;
-  const f16* kref; int64_t ldkr;
-  int64_t k_hs, kr_hs;   // elements between two heads' K data (token-major: d; head-major: tokens * d)
-  const f16* vtref; int64_t ldvtr;
-  const int* ref_index;
-  f16* out; int64_t ldo;
-  int T, heads;
-  float scale_log2e;
-  int vt_vec_ok, vtref_vec_ok;
-};
 
 // raw v_exp_f32 (no denormal fix-up sequence around it: inputs here are <= ~THR and results below 2^-126
 // may flush to zero) and packed round-toward-zero fp32 -> fp16 conversion of the probabilities.  The
@@ -529,10 +515,11 @@ __global__ __launch_bounds__(NT) void temporal_attn_kernel(const f16* __restrict
 
 }  // namespace
 
-extern "C" int anip_ref_attention(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt,
-                                  int64_t ldvt, const void* kref, int64_t ldkr, const void* vtref, int64_t ldvtr,
-                                  const int* ref_index, void* out, int64_t ldo, int Nf, int T, int heads, int d,
-                                  float scale, int64_t k_head_stride, int64_t kref_head_stride, void* stream) {
+extern "C" int anip_ref_attention_ex(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt,
+                                     int64_t ldvt, const void* kref, int64_t ldkr, const void* vtref, int64_t ldvtr,
+                                     const int* ref_index, void* out, int64_t ldo, int Nf, int T, int heads, int d,
+                                     float scale, int64_t k_head_stride, int64_t kref_head_stride, int flags,
+                                     void* stream) {
   ANIP_REQUIRE(q && k && vt && out, "anip_ref_attention: null pointer");
   ANIP_REQUIRE(Nf > 0 && T > 0 && heads > 0, "anip_ref_attention: bad sizes");
   ANIP_REQUIRE((ldq & 7) == 0 && (ldk & 7) == 0 && (ldo & 3) == 0, "anip_ref_attention: ldq/ldk %% 8, ldo %% 4 required");
@@ -553,10 +540,19 @@ extern "C" int anip_ref_attention(const void* q, int64_t ldq, const void* k, int
   a.ref_index = ref_index;
   a.out = (f16*)out; a.ldo = ldo;
   a.T = T; a.heads = heads;
-  a.scale_log2e = scale * 1.4426950408889634f;
+  const bool q_log2 = (flags & ANIP_ATTN_Q_LOG2_SCALED) != 0;   // scores are base-2 exponents already: `scale` is not applied
+  a.scale_log2e = q_log2 ? 1.0f : scale * 1.4426950408889634f;
   a.vt_vec_ok = ((T & 7) == 0) && ((ldvt & 7) == 0);
   a.vtref_vec_ok = ((T & 7) == 0) && ((ldvtr & 7) == 0);
   hipStream_t s = (hipStream_t)stream;
+  if (q_log2) {
+    const int r = anip_ref_attn_dma_try(a, Nf, d, s);     // T % 256 == 0, d in {40, 80, 160}: the LDS-DMA kernel (attn_dma.hip)
+    if (r < 0) return r;
+    if (r > 0) {
+      ANIP_LAUNCH_CHECK("anip_ref_attention");
+      return 0;
+    }
+  }
   switch (d) {
     case 8: launch_ref_attn<8>(a, Nf, s); break;
     case 16: launch_ref_attn<16>(a, Nf, s); break;
@@ -572,6 +568,14 @@ extern "C" int anip_ref_attention(const void* q, int64_t ldq, const void* k, int
   }
   ANIP_LAUNCH_CHECK("anip_ref_attention");
   return 0;
+}
+
+extern "C" int anip_ref_attention(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt,
+                                  int64_t ldvt, const void* kref, int64_t ldkr, const void* vtref, int64_t ldvtr,
+                                  const int* ref_index, void* out, int64_t ldo, int Nf, int T, int heads, int d,
+                                  float scale, int64_t k_head_stride, int64_t kref_head_stride, void* stream) {
+  return anip_ref_attention_ex(q, ldq, k, ldk, vt, ldvt, kref, ldkr, vtref, ldvtr, ref_index, out, ldo, Nf, T, heads, d, scale,
+                               k_head_stride, kref_head_stride, 0, stream);
 }
 
 extern "C" int anip_temporal_attention(const void* qkv, void* out, int B, int F, int T, int heads, int d,

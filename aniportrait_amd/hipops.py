@@ -477,10 +477,11 @@ def batchnorm(x, gamma, beta, running_mean=None, running_var=None, eps=1e-5, rel
 
 
 def ref_attention(q, ldq, k, ldk, vt, ldvt, n_frames, T, heads, d, kref=None, ldkr=0, vtref=None, ldvtr=0,
-                  ref_index=None, scale=None, n_ref_frames=0, k_head_stride=0, kref_head_stride=0):
-    """see anip_ref_attention; returns (n_frames*T, heads*d) fp16.  `n_ref_frames` (frames whose
+                  ref_index=None, scale=None, n_ref_frames=0, k_head_stride=0, kref_head_stride=0, q_log2_scaled=False):
+    """see anip_ref_attention_ex; returns (n_frames*T, heads*d) fp16.  `n_ref_frames` (frames whose
     ref_index >= 0) is only used for the profiler's FLOP count.  k / kref head-major (gemm(head_dim=d) output, shape
-    (heads, tokens, d)): ldk = d and k_head_stride = tokens * d."""
+    (heads, tokens, d)): ldk = d and k_head_stride = tokens * d.  q_log2_scaled: q already carries scale * log2(e)
+    (ANIP_ATTN_Q_LOG2_SCALED: gemm(..., alpha=attn_q_alpha(d)) of the to_q projection)."""
     lib = L.load()
     _work(K_REF_ATTN, 4 * T * T * heads * d * (n_frames + (n_ref_frames if ref_index is not None else 0)),
           f"Nf{n_frames} T{T} h{heads} d{d} ref{n_ref_frames if ref_index is not None else 0}",
@@ -488,11 +489,16 @@ def ref_attention(q, ldq, k, ldk, vt, ldvt, n_frames, T, heads, d, kref=None, ld
     out = torch.empty((n_frames * T, heads * d), dtype=F16, device=q.device)
     if scale is None:
         scale = d ** -0.5
-    L.check(lib.anip_ref_attention(_p(q), ldq, _p(k), ldk, _p(vt), ldvt, _p(kref), ldkr, _p(vtref), ldvtr,
-                                   _p(ref_index), _p(out), heads * d, n_frames, T, heads, d, float(scale),
-                                   int(k_head_stride), int(kref_head_stride), _stream()),
+    L.check(lib.anip_ref_attention_ex(_p(q), ldq, _p(k), ldk, _p(vt), ldvt, _p(kref), ldkr, _p(vtref), ldvtr,
+                                      _p(ref_index), _p(out), heads * d, n_frames, T, heads, d, float(scale),
+                                      int(k_head_stride), int(kref_head_stride), 1 if q_log2_scaled else 0, _stream()),
             "anip_ref_attention")
     return out
+
+
+def attn_q_alpha(d, scale=None):
+    """alpha of the to_q projection GEMM for ref_attention(q_log2_scaled=True): softmax scale x log2(e)"""
+    return float((d ** -0.5 if scale is None else scale) * 1.4426950408889634)
 
 
 def temporal_attention(qkv, B, F, T, heads, d, scale=None):

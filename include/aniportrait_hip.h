@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ANIP_ABI_VERSION 11
+#define ANIP_ABI_VERSION 12
 
 int anip_version(void);
 const char* anip_last_error(void);
@@ -155,6 +155,18 @@ int anip_ref_attention(const void* q, int64_t ldq, const void* k, int64_t ldk, c
                        const void* kref, int64_t ldkr, const void* vtref, int64_t ldvtr,
                        const int* ref_index, void* out, int64_t ldo,
                        int Nf, int T, int heads, int d, float scale, int64_t k_head_stride, int64_t kref_head_stride, void* stream);
+/* The same with `flags`.  ANIP_ATTN_Q_LOG2_SCALED: q has been multiplied by scale * log2(e) by its producer (the `alpha` of
+ * the to_q projection anip_gemm: still one fp16 rounding of the fp32 accumulator), so q.k is the base-2 exponent of the
+ * softmax and `scale` is ignored.  It is what the engine passes: for T % 256 == 0 and d in {40, 80, 160} it selects the
+ * round-4 kernel (csrc/attn_dma.hip: LDS-DMA K / V^T ring, 256 queries per workgroup, running max folded into the score
+ * MFMA at d = 40); every other shape runs the first kernel with the flag honoured.  The base-2 exponents must stay
+ * below 6e4 in magnitude (the folded running max is carried as an fp16 hi/lo pair). */
+#define ANIP_ATTN_Q_LOG2_SCALED 1
+int anip_ref_attention_ex(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
+                          const void* kref, int64_t ldkr, const void* vtref, int64_t ldvtr,
+                          const int* ref_index, void* out, int64_t ldo,
+                          int Nf, int T, int heads, int d, float scale, int64_t k_head_stride, int64_t kref_head_stride,
+                          int flags, void* stream);
 
 /* ---- temporal self-attention ------------------------------------------------------------------
  * replaces VersatileAttention (src/models/motion_module.py:351-388): for every (b, pixel t, head):

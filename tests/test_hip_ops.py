@@ -350,6 +350,94 @@ def test_ref_attention_peaky_with_reference(d, T):
     close(out, torch.cat(refs, 0), f"ref_attention peaky d={d} T={T}", rtol=6e-3, arms=6e-3)
 
 
+def _attn_log2_case(ops, d, T, heads, Nf, ridx, seed, scale=1.0, head_major=True):
+    """q pre-multiplied by scale * log2(e) (ANIP_ATTN_Q_LOG2_SCALED), K head-major, V^T: the engine's operand layouts.
+    Returns (out, fp64 reference computed from the SAME rounded q)."""
+    Cc = heads * d
+    Nref = 2
+    qs = (rnd(Nf * T, Cc, seed=seed, scale=scale).float() * ops.attn_q_alpha(d)).half().to(DEV)
+    k = rnd(Nf * T, Cc, seed=seed + 1, scale=scale).to(DEV)
+    v = rnd(Nf * T, Cc, seed=seed + 2).to(DEV)
+    kref = rnd(Nref * T, Cc, seed=seed + 3, scale=scale).to(DEV)
+    vref = rnd(Nref * T, Cc, seed=seed + 4).to(DEV)
+    ref_index = torch.tensor(ridx, dtype=torch.int32, device=DEV)
+    k_hm = k.reshape(Nf * T, heads, d).permute(1, 0, 2).contiguous()
+    kr_hm = kref.reshape(Nref * T, heads, d).permute(1, 0, 2).contiguous()
+    if head_major:
+        out = ops.ref_attention(qs, Cc, k_hm, d, v.t().contiguous(), Nf * T, Nf, T, heads, d, kref=kr_hm, ldkr=d,
+                                vtref=vref.t().contiguous(), ldvtr=Nref * T, ref_index=ref_index,
+                                k_head_stride=Nf * T * d, kref_head_stride=Nref * T * d, q_log2_scaled=True)
+    else:
+        out = ops.ref_attention(qs, Cc, k, Cc, v.t().contiguous(), Nf * T, Nf, T, heads, d, kref=kref, ldkr=Cc,
+                                vtref=vref.t().contiguous(), ldvtr=Nref * T, ref_index=ref_index, q_log2_scaled=True)
+    refs = []
+    for n in range(Nf):
+        q_ = qs[n * T:(n + 1) * T].double().reshape(T, heads, d).transpose(0, 1)
+        k_ = k[n * T:(n + 1) * T].double().reshape(T, heads, d).transpose(0, 1)
+        v_ = v[n * T:(n + 1) * T].double().reshape(T, heads, d).transpose(0, 1)
+        r = int(ref_index[n])
+        if r >= 0:
+            k_ = torch.cat([k_, kref[r * T:(r + 1) * T].double().reshape(T, heads, d).transpose(0, 1)], 1)
+            v_ = torch.cat([v_, vref[r * T:(r + 1) * T].double().reshape(T, heads, d).transpose(0, 1)], 1)
+        p = torch.softmax(q_ @ k_.transpose(-1, -2) * math.log(2.0), dim=-1)     # 2^(q.k) normalised
+        refs.append((p @ v_).transpose(0, 1).reshape(T, Cc).float())
+    return out, torch.cat(refs, 0)
+
+
+@pytest.mark.parametrize("d", [40, 80, 160])
+@pytest.mark.parametrize("T", [256, 512, 1024])
+def test_ref_attention_log2_scaled(d, T):
+    """the round-4 kernel (csrc/attn_dma.hip: T % 256 == 0, d in {40, 80, 160}) on the engine's operand layouts, with a
+    CFG-unconditional frame, both reference samples and more (frame, head) pairs than XCDs"""
+    ops = _ops()
+    out, ref = _attn_log2_case(ops, d, T, heads=8, Nf=3, ridx=[-1, 1, 0], seed=300 + d + T)
+    close(out, ref, f"ref_attention log2-scaled d={d} T={T}", rtol=4e-3, arms=4e-3)
+
+
+@pytest.mark.parametrize("d,T", [(40, 100), (88, 256), (40, 320), (64, 512)])
+def test_ref_attention_log2_scaled_other_shapes(d, T):
+    """shapes the round-4 kernel does not take: the flag is honoured by the first kernel"""
+    ops = _ops()
+    out, ref = _attn_log2_case(ops, d, T, heads=2, Nf=3, ridx=[-1, 1, 0], seed=340 + d + T)
+    close(out, ref, f"ref_attention log2-scaled (first kernel) d={d} T={T}", rtol=4e-3, arms=4e-3)
+
+
+@pytest.mark.parametrize("d,T", [(40, 1024), (80, 1024), (160, 256)])
+def test_ref_attention_log2_scaled_peaky(d, T):
+    """large-|score| inputs (peaky softmax): the folded running max (d = 40) and the subtracted one (d = 80, 160)"""
+    ops = _ops()
+    out, ref = _attn_log2_case(ops, d, T, heads=8, Nf=2, ridx=[-1, 0], seed=360 + d, scale=2.0)
+    close(out, ref, f"ref_attention log2-scaled peaky d={d} T={T}", rtol=6e-3, arms=6e-3)
+    out, ref = _attn_log2_case(ops, d, T, heads=8, Nf=2, ridx=[1, -1], seed=365 + d, scale=2.0, head_major=False)
+    close(out, ref, f"ref_attention log2-scaled peaky token-major d={d} T={T}", rtol=6e-3, arms=6e-3)
+
+
+@pytest.mark.parametrize("d", [40, 80, 160])
+@pytest.mark.parametrize("order", ["up", "down", "spike", "low"])
+def test_ref_attention_log2_scaled_lazy_rescale(d, order):
+    """ramps of 60 log2 units over the keys (ascending: a rescale on many tiles; descending: later tiles underflow),
+    isolated spikes, and scores that are all far BELOW zero (the first tile must set the running max, not 0)"""
+    ops = _ops()
+    heads, Nf, T = 1, 1, 512
+    ramp = torch.arange(T).float() / T
+    if order == "down":
+        ramp = ramp.flip(0)
+    if order == "spike":
+        ramp = torch.zeros(T)
+        ramp[[70, 71, 200, 333, T - 1]] = torch.tensor([0.3, 0.31, 0.6, 0.9, 1.0])
+    if order == "low":
+        ramp = -2.0 - ramp
+    q = torch.ones(T, d)
+    q[1::2] *= 0.5                                              # half the queries see half the ramp
+    qs = (q * (1.0 / d)).half()                                 # q.k = ramp * 60 exactly representable pieces
+    k = (ramp[:, None] * 60.0 * torch.ones(T, d)).half()
+    v = rnd(T, d, seed=375)
+    out = ops.ref_attention(qs.to(DEV), d, k.to(DEV), d, v.t().contiguous().to(DEV), T, Nf, T, heads, d, q_log2_scaled=True)
+    p = torch.softmax(qs.double() @ k.double().t() * math.log(2.0), dim=-1)
+    close(out, (p @ v.double()).float(), f"ref_attention log2-scaled lazy rescale d={d} {order}", rtol=6e-3, arms=6e-3)
+
+
+
 @pytest.mark.parametrize("M,N,K,hd", [(32768, 320, 320, 40), (8192, 640, 640, 80), (2048, 1280, 1280, 160), (100, 320, 64, 40),
                                       (16384, 1408, 1408, 88), (33003, 320, 136, 40)])
 def test_gemm_head_major_output(M, N, K, hd):

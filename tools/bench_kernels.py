@@ -92,14 +92,14 @@ def bench_conv(N, H, Cin, Cout, tag, up=False, stride=1, res=False, rb=False, pa
 def bench_attn(Nf, T, heads, d, tag):
     """operand layouts of engine.transformer_block: Q token-major, K head-major (heads, tokens, d), V^T (C, tokens)"""
     C = heads * d
-    q = r16(Nf * T, C)
+    q = (r16(Nf * T, C).float() * ops.attn_q_alpha(d)).half()     # what gemm(alpha=attn_q_alpha(d)) of to_q delivers
     k = r16(heads, Nf * T, d)
     vt = r16(C, Nf * T)
     kref, vtref = r16(heads, 2 * T, d), r16(C, 2 * T)
     ridx = torch.tensor([-1] * (Nf // 2) + [1] * (Nf - Nf // 2), dtype=torch.int32, device=DEV)
     t = timeit(lambda: ops.ref_attention(q, C, k, d, vt, Nf * T, Nf, T, heads, d, kref=kref, ldkr=d, vtref=vtref,
                                          ldvtr=2 * T, ref_index=ridx, k_head_stride=Nf * T * d,
-                                         kref_head_stride=2 * T * d))
+                                         kref_head_stride=2 * T * d, q_log2_scaled=True))
     fl = 4 * T * T * C * (Nf // 2) + 4 * T * 2 * T * C * (Nf - Nf // 2)
     print(json.dumps(dict(kernel="ref_attention", tag=tag, Nf=Nf, T=T, d=d, ms=t * 1e3, us=t * 1e6, tflops=fl / t / 1e12)), flush=True)
 

@@ -23,14 +23,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
   asm volatile(ASM : "+v"(C7))
 
 template <int OP>
-__global__ __launch_bounds__(1024) void rate_kernel(float* out, unsigned long long* cyc, int iters) {
+__global__ __launch_bounds__(1024) void rate_kernel(float* out, unsigned long long* cyc, unsigned long long* rt, int iters) {
   float c[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) c[i] = 0.001f * (threadIdx.x + 1) + i;
   f32x4 acc4[4] = {};
   f32x16 acc16[2] = {};
+  f32x16 accA = {}, accB = {};
   f16x8 a8 = {(f16)1, (f16)2, (f16)3, (f16)4, (f16)5, (f16)6, (f16)7, (f16)8};
   __syncthreads();
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
   const unsigned long long t0 = __builtin_readcyclecounter();
   for (int it = 0; it < iters; ++it) {
     if (OP == 0) { CHAINS8("v_exp_f32 %0, %0", c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]); }
@@ -136,6 +138,73 @@ __global__ __launch_bounds__(1024) void rate_kernel(float* out, unsigned long lo
                    "v_max3_f32 %0, %0, %5, %6\n v_max3_f32 %0, %0, %6, %7\n v_max3_f32 %0, %0, %7, %1\n v_max3_f32 %0, %0, %1, %3"
                    : "+v"(c[0]) : "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]));
     }
+    // the planned reference-attention unit (32 queries x 64 keys at d = 40, scale and running max folded into the
+    // contraction): 14 x 32x32x16 + 32 exp + 16 cvt_pk + 16 max3 + 8 fma, ~5 VALU behind every MFMA
+    if (OP == 25 || OP == 26 || OP == 27) {
+#pragma unroll
+      for (int k = 0; k < 14; ++k) {
+        if (OP == 25) acc16[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8, a8, acc16[k & 1], 0, 0, 0);
+        if (OP == 26) {   // the 8 P V MFMAs accumulate in AGPRs, the 6 score MFMAs in VGPRs
+          if (k < 6) acc16[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8, a8, acc16[k & 1], 0, 0, 0);
+          else if (k & 1) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %1, %0" : "+a"(accA) : "v"(a8));
+          else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %1, %0" : "+a"(accB) : "v"(a8));
+        }
+        if (OP == 27) {
+          if (k & 1) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %1, %0" : "+a"(accA) : "v"(a8));
+          else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %1, %0" : "+a"(accB) : "v"(a8));
+        }
+        if (k < 8) {
+          asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
+          asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1\n v_cvt_pkrtz_f16_f32 %2, %2, %3" : "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+        } else if (k < 12) {
+          asm volatile("v_max3_f32 %0, %0, %1, %2\n v_max3_f32 %3, %3, %1, %2\n v_max3_f32 %1, %1, %0, %2\n v_max3_f32 %2, %2, %1, %3" : "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+        } else {
+          asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3" : "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+        }
+      }
+    }
+    if (OP == 28) {   // that VALU multiset alone
+#pragma unroll
+      for (int k = 0; k < 14; ++k) {
+        if (k < 8) {
+          asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
+          asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1\n v_cvt_pkrtz_f16_f32 %2, %2, %3" : "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+        } else if (k < 12) {
+          asm volatile("v_max3_f32 %0, %0, %1, %2\n v_max3_f32 %3, %3, %1, %2\n v_max3_f32 %1, %1, %0, %2\n v_max3_f32 %2, %2, %1, %3" : "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+        } else {
+          asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3" : "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+        }
+      }
+    }
+    if (OP == 29) {   // 2 x 32x32x16 (AGPR accumulators) + 16 v_fma: op 17 with the accumulators out of the VGPR file
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %1, %0" : "+a"(accA) : "v"(a8));
+      CHAINS8("v_fma_f32 %0, %0, %0, %0", c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %1, %0" : "+a"(accB) : "v"(a8));
+      CHAINS8("v_fma_f32 %0, %0, %0, %0", c[0], c[1], c[2], c[3], c[4], c[5], c[6], c[7]);
+    }
+    if (OP == 30 || OP == 31) {   // PHASED unit (no in-wave interleave): 6 score MFMAs | the VALU block | 8 P V MFMAs (AGPR accumulators)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) acc16[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8, a8, acc16[k & 1], 0, 0, 0);
+      if (OP == 31) { c[4] += acc16[0][3]; c[5] += acc16[1][7]; }   // the softmax waits for the scores
+#pragma unroll
+      for (int k = 0; k < 14; ++k) {
+        if (k < 8) {
+          asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3" : "+v"(c[0]), "+v"(c[1]), "+v"(c[2]), "+v"(c[3]));
+          asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1\n v_cvt_pkrtz_f16_f32 %2, %2, %3" : "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+        } else if (k < 12) {
+          asm volatile("v_max3_f32 %0, %0, %1, %2\n v_max3_f32 %3, %3, %1, %2\n v_max3_f32 %1, %1, %0, %2\n v_max3_f32 %2, %2, %1, %3" : "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+        } else {
+          asm volatile("v_fma_f32 %0, %0, %0, %0\n v_fma_f32 %1, %1, %1, %1\n v_fma_f32 %2, %2, %2, %2\n v_fma_f32 %3, %3, %3, %3" : "+v"(c[4]), "+v"(c[5]), "+v"(c[6]), "+v"(c[7]));
+        }
+      }
+      f16x8 pb = a8;
+      if (OP == 31) pb[0] = (f16)c[4];                              // the P V MFMAs wait for the probabilities
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (k & 1) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(accA) : "v"(a8), "v"(pb));
+        else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(accB) : "v"(a8), "v"(pb));
+      }
+    }
     if (OP == 21) {   // the same MFMA multiset alone
 #pragma unroll
       for (int k = 0; k < 6; ++k) acc16[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a8, a8, acc16[k & 1], 0, 0, 0);
@@ -144,20 +213,21 @@ __global__ __launch_bounds__(1024) void rate_kernel(float* out, unsigned long lo
     }
   }
   const unsigned long long t1 = __builtin_readcyclecounter();
+  const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) s += c[i];
 #pragma unroll
   for (int k = 0; k < 4; ++k) s += acc4[k][0];
-  s += acc16[0][0] + acc16[1][0];
+  s += acc16[0][0] + acc16[1][0] + accA[0] + accB[0];
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
-  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
+  if ((threadIdx.x & 63) == 0) { cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0; rt[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = r1 - r0; }
 }
 
-extern "C" int exp_rate(int op, int blocks, int threads, int iters, float* out, unsigned long long* cyc, void* stream) {
+extern "C" int exp_rate(int op, int blocks, int threads, int iters, float* out, unsigned long long* cyc, unsigned long long* rt, void* stream) {
   hipStream_t s = (hipStream_t)stream;
-#define L(N) case N: hipLaunchKernelGGL(rate_kernel<N>, dim3(blocks), dim3(threads), 0, s, out, cyc, iters); break;
-  switch (op) { L(0) L(1) L(2) L(3) L(4) L(5) L(6) L(7) L(8) L(9) L(10) L(11) L(12) L(13) L(14) L(15) L(16) L(17) L(18) L(19) L(20) L(21) L(22) L(23) L(24) default: return -1; }
+#define L(N) case N: hipLaunchKernelGGL(rate_kernel<N>, dim3(blocks), dim3(threads), 0, s, out, cyc, rt, iters); break;
+  switch (op) { L(0) L(1) L(2) L(3) L(4) L(5) L(6) L(7) L(8) L(9) L(10) L(11) L(12) L(13) L(14) L(15) L(16) L(17) L(18) L(19) L(20) L(21) L(22) L(23) L(24) L(25) L(26) L(27) L(28) L(29) L(30) L(31) default: return -1; }
 #undef L
   return hipGetLastError() == hipSuccess ? 0 : -2;
 }
