@@ -213,6 +213,28 @@ __global__ __launch_bounds__(NT2, (D <= 40 ? 4 : 2)) void ref_attn_dma_kernel(co
 
     // ---- S^T = K Q^T (- m): two 32-key x 32-query tiles -------------------------------------------------------------------
     f32x16 s0, s1;
+#if defined(ANIP_ATTN_AGPR) && defined(__HIP_DEVICE_COMPILE__)
+    // The `a` operand below makes the compiler select the AGPR form for every BUILTIN MFMA of this kernel (the P V ones:
+    // O^T then lives in the accumulator file, and all their hazards stay the compiler's business); the score MFMAs must
+    // deliver into VGPRs (the VALU reads them), so they are written out by hand: operands complete (the compiler waits for
+    // the LDS reads feeding an asm statement), alternating accumulators, zero as the first addend, and 12 wait states
+    // behind the last one before the VALU may read its result (8 passes + margin; the block is opaque to the hazard recognizer).
+    {
+      f16x8 ka[DQ], kb[DQ];
+#pragma unroll
+      for (int kk = 0; kk < DQ; ++kk) {
+        const bool last = kk == DQ - 1;
+        ka[kk] = *(const f16x8*)(st + (last ? klast0 : koff + kk * 32));
+        kb[kk] = *(const f16x8*)(st + (last ? klast1 : koff + kk * 32 + KHALF));
+      }
+      asm volatile("" ::"a"(0.0f));
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %2, %4, 0\n v_mfma_f32_32x32x16_f16 %1, %3, %4, 0" : "=&v"(s0), "=&v"(s1) : "v"(ka[0]), "v"(kb[0]), "v"(qf[0]));
+#pragma unroll
+      for (int kk = 1; kk < DQ; ++kk)
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %2, %4, %0\n v_mfma_f32_32x32x16_f16 %1, %3, %4, %1" : "+v"(s0), "+v"(s1) : "v"(ka[kk]), "v"(kb[kk]), "v"(qf[kk]));
+      asm volatile("s_nop 7\n s_nop 3" : "+v"(s0), "+v"(s1));
+    }
+#else
 #pragma unroll
     for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
 #pragma unroll
@@ -223,6 +245,7 @@ __global__ __launch_bounds__(NT2, (D <= 40 ? 4 : 2)) void ref_attn_dma_kernel(co
       s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, qf[kk], s0, 0, 0, 0);
       s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, qf[kk], s1, 0, 0, 0);
     }
+#endif
     // ---- tile maximum (one query per lane; lane ^ 32 holds the other 32 keys) ---------------------------------------------
     float mx = fmaxf(fmaxf(s0[0], s0[1]), s0[2]);
 #pragma unroll
@@ -298,18 +321,11 @@ __global__ __launch_bounds__(NT2, (D <= 40 ? 4 : 2)) void ref_attn_dma_kernel(co
 #pragma unroll
       for (int dt = 0; dt < DO; ++dt) {
         const f16x8 av = *(const f16x8*)(st + voff[gk] + dt * 4096);
-#if defined(ANIP_ATTN_AGPR) && defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(o[dt]) : "v"(av), "v"(pb[gk].h));
-#else
         o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, pb[gk].h, o[dt], 0, 0, 0);
-#endif
       }
     }
   }
-  // the inline-asm MFMAs are opaque to the hazard recognizer: results are readable 8 passes + 3 states after the last issue
-#ifdef ANIP_ATTN_AGPR
-  asm volatile("s_nop 7\n s_nop 7\n s_nop 7" ::: "memory");
-#endif
+
 
   // ---- epilogue -------------------------------------------------------------------------------------------------------------
   float l_tot;

@@ -930,12 +930,20 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
       // path) takes the tight epilogue below; ragged tiles take the general per-element-guarded one.
       const bool has_rb = p.rowbias != nullptr, has_res = p.residual != nullptr;
       // (32-bit per-lane byte offsets: the output / residual extents must stay below 4 GiB)
-      const bool tight = !(dbg & 8) && p.alpha == 1.0f && m0 + BM2 <= p.M && n0 + BN <= p.N &&
+      const bool tight = !(dbg & 8) && m0 + BM2 <= p.M && n0 + BN <= p.N &&
                          (p.out_f32 ? (p.ldo & 3) == 0 : ((p.head_dim > 0 ? p.head_dim : p.ldo) & 7) == 0) &&
                          (!has_res || (p.ldr & 7) == 0) &&
                          (acc_has_bias || (p.bias == nullptr && !has_rb)) &&
                          (int64_t)p.M * p.ldo * (p.out_f32 ? 4 : 2) < (1ll << 32) &&
                          (!has_res || (int64_t)p.M * p.ldr * 2 < (1ll << 32));
+      if (tight && alpha != 1.0f) {      // (acc_has_bias implies alpha == 1: nothing but products in the accumulators here)
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] *= alpha;
+      }
       if (!tight) {
         // general path.  The accumulators may ALREADY hold the bias (and a block-uniform row-group bias): a full tile with
         // 16-B accessible bias terms takes `acc_has_bias` whether or not the rest of the tight conditions hold (output of

@@ -275,7 +275,9 @@ def transformer_block(net, p, h, Nf, T, heads, attn2_vec, rows_per_sample, ref=N
     # bytes) sits at a 4C-byte stride and the attention kernel's K-tile reads touch 2-3x the cache lines; head-major, a
     # 64-key tile of a head is one contiguous run (measured at 64x64, d = 40: 1.75 ms fused rows, 1.60 ms separate
     # matrices, 1.54 ms contiguous rows — against +12 us for the second GEMM launch)
-    q = ops.gemm(nh, net.lin(p + ".attn1.to_q.weight"))
+    # Q leaves its projection multiplied by d^-1/2 log2(e) (the GEMM's alpha: still one fp16 rounding of the fp32 accumulator):
+    # the attention kernel then exponentiates q.k in base 2 with no per-score multiply (anip_ref_attention_ex)
+    q = ops.gemm(nh, net.lin(p + ".attn1.to_q.weight"), alpha=ops.attn_q_alpha(d))
     k = ops.gemm(nh, net.lin(p + ".attn1.to_k.weight"), head_dim=d)
     vt = ops.gemm(nh, net.lin(p + ".attn1.to_v.weight"), trans_out=True)  # V^T [C][Nf*T]
     kw = {}
@@ -285,7 +287,7 @@ def transformer_block(net, p, h, Nf, T, heads, attn2_vec, rows_per_sample, ref=N
         assert ref.bank.shape[1] == T, "reference bank token count differs from the denoising latents"
         kw = dict(kref=ref.kref, ldkr=d, kref_head_stride=ref.kref.shape[0] * d, vtref=ref.vtref,
                   ldvtr=ref.vtref.shape[1], ref_index=ref_index[0], n_ref_frames=ref_index[1])
-    a = ops.ref_attention(q, C, k, d, vt, vt.shape[1], Nf, T, heads, d, k_head_stride=Nf * T * d, **kw)
+    a = ops.ref_attention(q, C, k, d, vt, vt.shape[1], Nf, T, heads, d, k_head_stride=Nf * T * d, q_log2_scaled=True, **kw)
     # attn1 out-proj + residual (+ the collapsed attn2: one vector per sample)
     h = ops.gemm(a, net.lin(p + ".attn1.to_out.0.weight"), net.f32(p + ".attn1.to_out.0.bias"),
                  rowbias=attn2_vec, rows_per_group=rows_per_sample, residual=h)

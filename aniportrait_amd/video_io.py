@@ -1,8 +1,7 @@
 """Output side of the path: what the reference's scripts do with the frames the pipeline returns —
-`save_videos_grid` and its helpers (/root/reference/src/utils/util.py:51-104), plus the small host utilities the scripts
-import from the same module (`read_frames`, `get_fps`, `seed_everything`, `import_filename`, `delete_additional_ckpt`:
-util.py:17-48,107-130), so that `src.utils.util` can be served from this repository without cv2 / torchvision / av being
-importable at module load (they are imported where they are used).
+`save_videos_grid` and `save_videos_from_pil` (/root/reference/src/utils/util.py:51-104).  Every other name of that module
+(the PyAV readers, the training scripts' host helpers, `crop_face`) is out of the path's scope and keeps coming from the
+reference's own file through the `src/utils/util.py` shim.
 
 The reference builds every output frame on the host in fp32: `torchvision.utils.make_grid` of the (b, 3, h, w) batch of
 one time step, two transposes, `(x * 255).numpy().astype(uint8)`, `Image.fromarray` — per frame, in a Python loop
@@ -20,36 +19,6 @@ import numpy as np
 import torch
 
 
-def seed_everything(seed):
-    """util.py:17-25"""
-    import random
-    torch.manual_seed(seed)
-    torch.cuda.manual_seed_all(seed)
-    np.random.seed(seed % (2 ** 32))
-    random.seed(seed)
-
-
-def import_filename(filename):
-    """util.py:28-33: load a python file as the module `mymodule`"""
-    import importlib.util
-    import sys
-    spec = importlib.util.spec_from_file_location("mymodule", filename)
-    module = importlib.util.module_from_spec(spec)
-    sys.modules[spec.name] = module
-    spec.loader.exec_module(module)
-    return module
-
-
-def delete_additional_ckpt(base_path, num_keep):
-    """util.py:36-48: keep the `num_keep` highest-numbered `checkpoint-<n>` directories under base_path"""
-    import shutil
-    ckpts = sorted((d for d in os.listdir(base_path) if d.startswith("checkpoint-")), key=lambda d: int(d.split("-")[-1]))
-    for d in ckpts[: max(0, len(ckpts) - num_keep)]:
-        full = os.path.join(base_path, d)
-        if os.path.exists(full):
-            shutil.rmtree(full)
-
-
 def _av():
     try:
         import av
@@ -61,7 +30,9 @@ def _av():
 
 def display_bytes(videos, rescale=False):
     """float video (b, 3, t, h, w) in [0, 1] ([-1, 1] with rescale) -> uint8 (b, t, h, w, 3), the bytes the reference
-    writes: uint8(x * 255) in fp32, truncating (util.py:95-97).  Runs on the tensor's device."""
+    writes: uint8(x * 255) in fp32, truncating (util.py:95-97).  Runs on the tensor's device.  Precondition: the values
+    are inside the stated range (the pipeline clamps: decode_latents); a float outside [0, 256) converts to an
+    implementation-defined byte on the device as it does in numpy, and the two need not agree there."""
     x = videos.float()
     if rescale:
         x = (x + 1.0) / 2.0
@@ -126,25 +97,3 @@ def save_videos_grid(videos, path, rescale=False, n_rows=6, fps=8):
         u8 = display_bytes(videos, rescale)
     frames = grid_frames(u8, n_rows, border=127 if rescale else 0)
     save_videos_from_pil([Image.fromarray(fr) for fr in frames], path, fps)
-
-
-def read_frames(video_path):
-    """util.py:107-122: every frame of the first video stream as an RGB PIL image"""
-    from PIL import Image
-    av = _av()
-    container = av.open(video_path)
-    stream = next(s for s in container.streams if s.type == "video")
-    frames = []
-    for packet in container.demux(stream):
-        for frame in packet.decode():
-            frames.append(Image.frombytes("RGB", (frame.width, frame.height), frame.to_rgb().to_ndarray()))
-    return frames
-
-
-def get_fps(video_path):
-    """util.py:125-130"""
-    av = _av()
-    container = av.open(video_path)
-    fps = next(s for s in container.streams if s.type == "video").average_rate
-    container.close()
-    return fps

@@ -1,14 +1,12 @@
-"""replaces /root/reference/src/utils/util.py for the output side of the path: `save_videos_grid`,
-`save_videos_from_pil`, `read_frames`, `get_fps` (scripts/pose2vid.py:26, scripts/audio2vid.py:27, scripts/vid2vid.py:26,
-scripts/vid2pose.py:7) and the host helpers of the training scripts (`seed_everything`, `import_filename`,
-`delete_additional_ckpt`).  Any other name (`crop_face` of the Gradio app) is served from the reference's own module —
-the next `src/utils/util.py` on the namespace package's path — loaded on first use."""
+"""replaces /root/reference/src/utils/util.py for the output side of the path: `save_videos_grid`
+and `save_videos_from_pil` (scripts/pose2vid.py:26, scripts/audio2vid.py:27, scripts/vid2vid.py:26).  Any other name
+(`read_frames`, `get_fps`, `crop_face`, the training scripts' host helpers) is served from the reference's own module — the
+next `src/utils/util.py` on the namespace package's path — loaded on first use."""
 import importlib.util
 import os
 import sys
 
-from aniportrait_amd.video_io import (delete_additional_ckpt, get_fps, import_filename, read_frames,  # noqa: F401
-                                      save_videos_from_pil, save_videos_grid, seed_everything)
+from aniportrait_amd.video_io import save_videos_from_pil, save_videos_grid  # noqa: F401
 
 _reference = None
 

@@ -146,9 +146,11 @@ def batchnorm(x, gamma, beta, running_mean=None, running_var=None, eps=1e-5, rel
 
 
 def ref_attention(q, ldq, k, ldk, vt, ldvt, n_frames, T, heads, d, kref=None, ldkr=0, vtref=None, ldvtr=0,
-                  ref_index=None, scale=None, n_ref_frames=0, k_head_stride=0, kref_head_stride=0):
+                  ref_index=None, scale=None, n_ref_frames=0, k_head_stride=0, kref_head_stride=0, q_log2_scaled=False):
     C = heads * d
     scale = d ** -0.5 if scale is None else scale
+    if q_log2_scaled:       # q carries scale * log2(e): softmax of 2^(q.k)
+        scale = 0.6931471805599453
     Q = q[:, :C].float().reshape(n_frames, T, heads, d).permute(0, 2, 1, 3)
     if k_head_stride:       # head-major (heads, tokens, d)
         k = k.reshape(heads, -1, d).permute(1, 0, 2).reshape(-1, C)
@@ -167,6 +169,10 @@ def ref_attention(q, ldq, k, ldk, vt, ldvt, n_frames, T, heads, d, kref=None, ld
         p = torch.softmax(Q[n] @ Kn.transpose(-1, -2) * scale, dim=-1)
         out[n] = (p @ Vn).permute(1, 0, 2).reshape(T, C)
     return out.reshape(n_frames * T, C).to(F16)
+
+
+def attn_q_alpha(d, scale=None):
+    return float((d ** -0.5 if scale is None else scale) * 1.4426950408889634)
 
 
 def temporal_attention(qkv, B, Fr, T, heads, d, scale=None):

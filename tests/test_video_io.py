@@ -96,18 +96,3 @@ def test_gif_file_and_unsupported_suffix(tmp_path):
     except ImportError:
         with pytest.raises(ImportError, match="PyAV"):
             video_io.save_videos_grid(v, str(tmp_path / "clip.mp4"))
-
-
-def test_host_helpers(tmp_path):
-    for n in (1, 5, 12, 30):
-        (tmp_path / f"checkpoint-{n}").mkdir()
-    (tmp_path / "other").mkdir()
-    video_io.delete_additional_ckpt(str(tmp_path), 2)
-    assert sorted(d.name for d in tmp_path.iterdir()) == ["checkpoint-12", "checkpoint-30", "other"]
-    f = tmp_path / "cfg.py"
-    f.write_text("VALUE = 41 + 1\n")
-    assert video_io.import_filename(str(f)).VALUE == 42
-    video_io.seed_everything(5)
-    a = torch.rand(3)
-    video_io.seed_everything(5)
-    assert torch.equal(a, torch.rand(3))

@@ -97,6 +97,11 @@ def bench_attn(Nf, T, heads, d, tag):
     vt = r16(C, Nf * T)
     kref, vtref = r16(heads, 2 * T, d), r16(C, 2 * T)
     ridx = torch.tensor([-1] * (Nf // 2) + [1] * (Nf - Nf // 2), dtype=torch.int32, device=DEV)
+    import os
+    if os.environ.get("ATTN_ZERO"):       # all-zero operands: same instruction stream, no data toggling (clock / power check)
+        for x in (q, k, vt, kref, vtref):
+            x.zero_()
+        tag += " zeros"
     t = timeit(lambda: ops.ref_attention(q, C, k, d, vt, Nf * T, Nf, T, heads, d, kref=kref, ldkr=d, vtref=vtref,
                                          ldvtr=2 * T, ref_index=ridx, k_head_stride=Nf * T * d,
                                          kref_head_stride=2 * T * d, q_log2_scaled=True))

@@ -29,14 +29,16 @@ def calib():
 
 
 def attn(T=4096, heads=8, d=40):
+    """the engine's operand layouts: Q token-major and pre-multiplied by d^-1/2 log2 e, K head-major, V^T"""
     C = heads * d
-    qk = r16(NF * T, 2 * C)
+    q = (r16(NF * T, C).float() * ops.attn_q_alpha(d)).half()
+    k = r16(heads, NF * T, d)
     vt = r16(C, NF * T)
-    kref, vtref = r16(2 * T, C), r16(C, 2 * T)
+    kref, vtref = r16(heads, 2 * T, d), r16(C, 2 * T)
     ridx = torch.tensor([-1] * (NF // 2) + [1] * (NF - NF // 2), dtype=torch.int32, device=DEV)
     for _ in range(REP):
-        ops.ref_attention(qk, 2 * C, qk[:, C:], 2 * C, vt, NF * T, NF, T, heads, d, kref=kref, ldkr=C, vtref=vtref,
-                          ldvtr=2 * T, ref_index=ridx)
+        ops.ref_attention(q, C, k, d, vt, NF * T, NF, T, heads, d, kref=kref, ldkr=d, vtref=vtref, ldvtr=2 * T,
+                          ref_index=ridx, k_head_stride=NF * T * d, kref_head_stride=2 * T * d, q_log2_scaled=True)
     torch.cuda.synchronize()
 
 
