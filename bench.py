@@ -321,6 +321,17 @@ def main():
     assert repeats == 0 or worst >= 60.0, f"a repeated clip differs from its first run: PSNR {worst:.1f} dB"
     if 0 in first and 1 in first:
         assert not torch.equal(first[0], first[1]), "two different clips produced the same video"
+    # independent clips really are independent: every rank's clip differs from every other rank's — a SCALE run
+    # cannot silently time N copies of one cached result.  A 16-number signature of clip 0 per rank, gathered outside the timed region.
+    ranks_distinct = None
+    if world > 1 and not a.long_clip and 0 in first:
+        v0 = first[0].double().flatten()
+        idx = torch.linspace(0, v0.numel() - 1, 15, device=v0.device).long()
+        sig = torch.cat([v0.mean()[None], v0[idx]]).to(device)
+        sigs = [torch.empty_like(sig) for _ in range(world)]
+        torch.distributed.all_gather(sigs, sig)
+        ranks_distinct = all(not torch.equal(sigs[i], sigs[j]) for i in range(world) for j in range(i))
+        assert ranks_distinct, "two ranks produced the same clip: the per-rank inputs / weights are not independent"
 
     if rank == 0:
         frames = (1 if a.long_clip else n_gpus) * a.steps * L
@@ -340,7 +351,8 @@ def main():
                                     "per step per GPU (BASELINE.json configs[1])",
                         "frames_per_step": L, "parallelism": f"dp{n_gpus} over independent clips"}),
             "repeat_check": {"repeated_clips": repeats, "bit_identical": bool(repeats and worst == float("inf")),
-                             "min_psnr_db": None if worst == float("inf") else worst},
+                             "min_psnr_db": None if worst == float("inf") else worst,
+                             "rank_clips_pairwise_distinct": ranks_distinct},
         }
         is_c2 = (H == 512 and L == 16 and a.ddim_steps == 25)
         if a.async_output and not a.long_clip:

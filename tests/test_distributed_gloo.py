@@ -164,7 +164,7 @@ def test_two_rank_long_clip_pipeline_matches_reference(case, L):
 
 def _long_clip_inputs():
     """L = 78 at 64x64 with 8-frame windows overlapping by 2: 13 windows per DDIM step (the window count of BASELINE
-    configs[3]: L = 150, 16-frame windows), the last one wrapping around the clip end, offsets moving with the step"""
+    configs[3]: L = 150, 16-frame windows), the last one wrapping around the clip end (the same windows at every DDIM step: step 0 is what the reference passes)"""
     from aniportrait_amd.synthetic import synth_latents, synth_pose_frames, synth_ref_image
     H = W = 64
     L = 78

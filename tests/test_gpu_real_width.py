@@ -163,9 +163,34 @@ def test_c5_768_one_step_vs_reference_fixture(real_pipe):
 
 
 @torch.no_grad()
+def test_c2_full_25_step_schedule_vs_reference_fixture(real_pipe):
+    """BASELINE configs[1] IN FULL — 512x512, L=16, CFG 3.5, the whole 25-step trailing / zero-SNR / v-prediction DDIM schedule
+    that bench.py times — against the reference's own pipeline on PyTorch-CPU fp32 (72 CPU-minutes in the build container:
+    oracle/make_golden_real_pipeline.py c2_25step): all 16 decoded frames, whole and worst frame >= 40 dB, and the latent
+    SNR after every one of the 25 steps (printed: the fp16 error accumulates over the schedule)"""
+    pipe, _ = real_pipe
+    vid, lats, gold, i = _fixture_case(pipe, "c2_25step")
+    p, worst, lat_db = _report("C2 25 steps", vid, lats, gold, i)
+    assert vid.shape == (1, 3, 16, 512, 512) and len(gold["frames"]) == 16 and len(lats) == 25
+    assert p >= PSNR_BAR and worst >= PSNR_BAR and min(lat_db) >= 40.0
+    assert abs(float(vid.double().mean()) - float(gold["video_mean"])) < 2e-3
+
+
+@torch.no_grad()
+def test_c5_768_four_steps_vs_reference_fixture(real_pipe):
+    """BASELINE configs[4] geometry (768x768, L=16) at 4 DDIM steps against the reference's own CPU pipeline (4 stored frames)"""
+    pipe, _ = real_pipe
+    vid, lats, gold, i = _fixture_case(pipe, "c5_4step")
+    p, worst, lat_db = _report("C5 4 steps", vid, lats, gold, i)
+    assert vid.shape == (1, 3, 16, 768, 768) and len(lats) == 4
+    assert p >= PSNR_BAR and worst >= PSNR_BAR and min(lat_db) >= 40.0
+
+
+@torch.no_grad()
 def test_l40_wraparound_windows_vs_reference_fixture(real_pipe):
     """real width, L=40, 3 steps: 4 overlapping 16-frame windows per step, the last one wrapping around the clip end
-    ([36..39, 0..11] at step 0), the window offsets moving with the step (context.py:15-42) — the C4 mechanism"""
+    ([36..39, 0..11]); the reference passes step 0 to the context scheduler at every DDIM step
+    (pipeline_pose2vid_long.py:488-501), so the windows are the same at every step — the C4 mechanism"""
     pipe, _ = real_pipe
     vid, lats, gold, i = _fixture_case(pipe, "l40_windows")
     p, worst, lat_db = _report("L40", vid, lats, gold, i)
