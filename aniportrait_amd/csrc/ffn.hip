@@ -330,7 +330,10 @@ extern "C" int anip_ffn_geglu(const void* x, const void* w1p, const float* b1p, 
   a.x = (const f16*)x; a.w1p = (const f16*)w1p; a.b1p = b1p; a.w2 = (const f16*)w2; a.b2 = b2;
   a.res = (const f16*)residual; a.out = (f16*)out; a.M = (int)M;
   constexpr int LDS = (320 / 64 + 2) * 128 * 128 + 320 * 128;
-  static bool attr_done = false;
+  static bool attr_done_dev[16] = {};    // the attribute is per device
+  int dev_ = 0;
+  if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ > 15) dev_ = 15;
+  bool& attr_done = attr_done_dev[dev_];
   if (!attr_done) {
     if (hipFuncSetAttribute((const void*)ffn_geglu_kernel<320>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
       anip_set_error("anip_ffn_geglu: cannot raise the dynamic LDS limit to %d bytes", LDS);

@@ -1230,21 +1230,27 @@ inline int gemm2_persistent() {
   static const int v = getenv("ANIP_GEMM2_PERSIST") ? atoi(getenv("ANIP_GEMM2_PERSIST")) : 1;
   return v;
 }
-inline int gemm2_cu_count() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0;
+inline int gemm2_device() {             // ordinal of the current device, clamped into the per-device caches below
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+  return dev < 16 ? dev : 15;
+}
+inline int gemm2_cu_count() {           // per device: partitions of one node may expose different CU counts
+  static int n[16] = {};
+  const int dev = gemm2_device();
+  if (n[dev] == 0) {
     hipDeviceProp_t prop;
-    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : -1;
+    n[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : -1;
   }
-  return n;
+  return n[dev];
 }
 
 template <int BM2, int BN, int NW, int WNW, int BKT, int NST, bool CONV, bool TRANS, int SCHED = 0>
 int launch_gemm2(const anip_gemm_params& p, hipStream_t stream, int splitk = 1) {
   constexpr int NT2 = NW * 64;
   constexpr int LDS = NST * (BM2 + BN) * BKT * 2;
-  static bool attr_done = false;
+  static bool attr_done_dev[16] = {};   // the attribute is per device
+  bool& attr_done = attr_done_dev[gemm2_device()];
   if (!attr_done) {
     auto kfn = gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS, SCHED>;
     if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {

@@ -105,6 +105,23 @@ def gather_frames(local_frames, local_idx, n_frames, dst=0, group=None, owner_fn
     assert list(local_idx) == list(owner_fn(rank)), "gather_frames: local_idx does not follow the sharding rule"
     g = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
     tail = tuple(local_frames.shape[1:])
+    if dist.get_backend(group) == "nccl":
+        # RCCL: one collective with every share padded to the largest (the exact-size point-to-point form below has only
+        # ever run on gloo — no multi-GPU box was available to the builds; it stays the CPU path until it has been measured
+        # over xGMI, where per-pair communicator setup and zero-share ranks are the open questions)
+        most = max(len(list(owner_fn(r))) for r in range(ws))
+        send = torch.zeros((most,) + tail, dtype=local_frames.dtype, device=dev)
+        send[: len(local_idx)] = local_frames
+        bufs = [torch.empty_like(send) for _ in range(ws)] if rank == dst else None
+        dist.gather(send, bufs, dst=g(dst), group=group)
+        if rank != dst:
+            return None
+        out = torch.empty((n_frames,) + tail, dtype=local_frames.dtype, device=dev)
+        for r in range(ws):
+            idx = list(owner_fn(r))
+            if idx:
+                out[torch.as_tensor(idx, dtype=torch.long, device=dev)] = bufs[r][: len(idx)]
+        return out
     if rank != dst:
         if len(local_idx):
             for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, local_frames.contiguous(), g(dst), group)]):

@@ -401,7 +401,7 @@ class Pose2VideoPipeline(_Base):
         re-packs its weights (a captured graph has the packed tensors' addresses baked in) and bounded to
         `max_cached_graphs` entries (`drop_cached_graphs()` empties it)."""
         unet = self.denoising_unet
-        tag = (id(unet), unet.packed().serial)
+        tag = (id(unet), unet.packed().serial, getattr(unet, "pool_epoch", 0))
         if self.__dict__.get("_runner_tag") != tag:
             self.__dict__["_runner_tag"] = tag
             self.__dict__["_runners"] = OrderedDict()
@@ -423,7 +423,7 @@ class Pose2VideoPipeline(_Base):
         """{(kind, key): _GraphedFn} for the once-per-clip networks; an entry dies with the module's packed weights
         (their addresses are baked into the graph) and the per-kind population is bounded like the step graphs"""
         cache = self.__dict__.setdefault("_aux_graphs", {})
-        tag = (id(module), module.packed().serial)
+        tag = (id(module), module.packed().serial, getattr(module, "pool_epoch", 0))
         live = {k: v for k, v in cache.items() if k[0] != kind or v[0] == tag}
         mine = [k for k in live if k[0] == kind]
         if (kind, key) not in live:

@@ -94,6 +94,13 @@ class _UNetBase(HipModel):
             self._attn2_cache.drop()
             for rb in self._ref_blocks.values():
                 rb.state.drop()
+        # every pipeline object that captured graphs over this module compares this counter in its cache tag: a second
+        # pipeline sharing the module drops its graphs instead of replaying them over freed buffers
+        self.__dict__["_pool_epoch"] = self.pool_epoch + 1
+
+    @property
+    def pool_epoch(self):
+        return self.__dict__.get("_pool_epoch", 0)
 
     # ------------------------------------------------------------------------------------------------
     def _engine_refs(self):

@@ -43,6 +43,13 @@ def _worker(rank, world, port, q):
         local = torch.stack([torch.full((3, 2), float(i), device=dev) for i in idx])
         out = D.gather_frames(local, idx, 7, 0)
         ok3 = (out is None) if rank != 0 else bool((out[:, 0, 0].cpu() == torch.arange(7.0)).all())
+        # uneven shares with a rank that owns NO frame (the LPT window deal of a short clip can leave ranks idle)
+        own = (lambda r: list(range(3)) if r == 0 else [])
+        idx = own(rank)
+        local = (torch.stack([torch.full((3, 2), float(i), device=dev) for i in idx]) if idx
+                 else torch.empty((0, 3, 2), device=dev))
+        out = D.gather_frames(local, idx, 3, 0, owner_fn=own)
+        ok3 = ok3 and ((out is None) if rank != 0 else bool((out[:, 0, 0].cpu() == torch.arange(3.0)).all()))
         q.put((rank, ok1, ok2, ok3))
     finally:
         dist.destroy_process_group()
