@@ -525,7 +525,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
     // start the accumulators from the per-column additive terms (bias and, when the block's rows share one row group,
     // the row-group bias): NB small L2-resident loads that travel with the prologue DMA, no registers, and nothing
     // left to fetch for them in the epilogue, where loads queue behind the tile's stores (see there).
-    const bool acc_has_bias = !TRANS && !(dbg & 8) && splitk <= 1 && p.alpha == 1.0f && m0 + BM2 <= p.M && n0 + BN <= p.N &&
+    const bool acc_has_bias = !TRANS && !(dbg & 8) && splitk <= 1 && p.alpha == 1.0f && p.ln_stats == nullptr && m0 + BM2 <= p.M && n0 + BN <= p.N &&
                               (p.bias != nullptr || p.rowbias != nullptr) &&
                               (p.rowbias == nullptr || (((p.ld_rowbias & 3) == 0) && ((((uintptr_t)p.rowbias) & 15) == 0)));
     const bool rb_uni = acc_has_bias && p.rowbias != nullptr &&
@@ -733,7 +733,73 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
         for (int j = 0; j < NB; ++j) asm volatile("" ::"v"(acc[i][j]));
       return;               // (ends a persistent walk, too)
     }
-    const float alpha = p.alpha;
+    float alpha = p.alpha;
+    // what the accumulators already carry of the per-column additive terms (see acc_has_bias above, and the fold below)
+    bool bias_in_acc = acc_has_bias, rb_in_acc = rb_uni;
+    if (p.ln_stats != nullptr) {
+      // LayerNorm folded into this GEMM (anip_gemm_params.ln_stats): A holds the RAW rows x, W carries gamma, and with
+      // (mean, rstd) of every row and s[n] = sum_k W[n][k]
+      //     LN(x) W^T = rstd (x W^T - mean s)      [+ beta W^T + b, which the caller passes as `bias`]
+      // is applied to the finished accumulators — the normalised tensor is never written or read.  Full tiles with 16-B
+      // accessible bias terms take the bias (and a block-uniform row-group bias) in here as well, so that the tight
+      // epilogue below finds them in the accumulators as it does for a plain GEMM.
+      const bool full = m0 + BM2 <= p.M && n0 + BN <= p.N;       // block-uniform
+      const float2* st2 = (const float2*)p.ln_stats;
+      if (!TRANS) {
+        const bool fold = full && (p.bias != nullptr || p.rowbias != nullptr) &&
+                          (p.rowbias == nullptr || (((p.ld_rowbias & 3) == 0) && ((((uintptr_t)p.rowbias) & 15) == 0)));
+        const bool rbu = fold && p.rowbias != nullptr && (m0 / p.rows_per_group == (m0 + BM2 - 1) / p.rows_per_group);
+        const float* rb_row = rbu ? p.rowbias + (int64_t)(m0 / p.rows_per_group) * p.ld_rowbias : nullptr;
+        float ar[FM], br[FM];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          const int row = m0 + wm * WTM + i * 16 + fr;
+          const float2 ms = row < p.M ? st2[row] : make_float2(0.f, 0.f);
+          ar[i] = ms.y * alpha;
+          br[i] = -ms.x * ms.y;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const int cb = n0 + tile_c(j) + fq * 4;
+          f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f}, b = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (full) {
+            sc = *(const f32x4*)(p.ln_colsum + cb);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (cb + r < p.N) sc[r] = p.ln_colsum[cb + r];
+          }
+          if (fold && p.bias != nullptr) b = *(const f32x4*)(p.bias + cb);
+          if (rbu) b += *(const f32x4*)(rb_row + cb);
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = ar[i] * acc[i][j][r] + (br[i] * sc[r] + b[r]);
+        }
+        if (fold) {
+          bias_in_acc = true;
+          rb_in_acc = rbu;
+        }
+      } else {
+        float sj[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const int n = n0 + tile_c(j) + fr;
+          sj[j] = n < p.N ? p.ln_colsum[n] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = m0 + wm * WTM + i * 16 + fq * 4 + r;
+            const float2 ms = row < p.M ? st2[row] : make_float2(0.f, 0.f);
+            const float a_ = ms.y * alpha, b_ = -ms.x * ms.y;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[i][j][r] = a_ * acc[i][j][r] + b_ * sj[j];
+          }
+      }
+      alpha = 1.0f;
+    }
     const int64_t obatch = (p.batch > 1) ? (int64_t)blockIdx.y * p.strideO : 0;
     const int tsel = fq & 1, csel = (fq >> 1) * 8;   // after row_swap: tile of the pair / column offset in it
 
@@ -904,7 +970,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
         float bv0[4], bg0[4], bv1[4], bg1[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const bool hb = p.bias != nullptr && !acc_has_bias;
+          const bool hb = p.bias != nullptr && !bias_in_acc;
           bv0[r] = (hb && pn + r < p.N) ? p.bias[pn + r] : 0.f;
           bg0[r] = (hb && pn + 16 + r < p.N) ? p.bias[pn + 16 + r] : 0.f;
           bv1[r] = (hb && pn + 32 + r < p.N) ? p.bias[pn + 32 + r] : 0.f;
@@ -933,7 +999,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
       const bool tight = !(dbg & 8) && m0 + BM2 <= p.M && n0 + BN <= p.N &&
                          (p.out_f32 ? (p.ldo & 3) == 0 : ((p.head_dim > 0 ? p.head_dim : p.ldo) & 7) == 0) &&
                          (!has_res || (p.ldr & 7) == 0) &&
-                         (acc_has_bias || (p.bias == nullptr && !has_rb)) &&
+                         (bias_in_acc || (p.bias == nullptr && !has_rb)) &&
                          (int64_t)p.M * p.ldo * (p.out_f32 ? 4 : 2) < (1ll << 32) &&
                          (!has_res || (int64_t)p.M * p.ldr * 2 < (1ll << 32));
       if (tight && alpha != 1.0f) {      // (acc_has_bias implies alpha == 1: nothing but products in the accumulators here)
@@ -950,7 +1016,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
         // 4 GiB or more, unaligned leading dimensions).  Round 2 added them a second time here — the decoded frames of a
         // 16-frame VAE batch at 512x512 / 768x768 (2^30+ output elements in the upsampler convs) carried every channel's
         // bias twice: the "46 dB at 512x512, 38 dB at 768x768" of the round-2 / round-3 parity runs.
-        const bool add_bias = !acc_has_bias, add_rb = !(acc_has_bias && rb_uni);
+        const bool add_bias = !bias_in_acc, add_rb = !(bias_in_acc && rb_in_acc);
 #pragma unroll
         for (int jp = 0; jp < NB / 2; ++jp) {
           const int n = n0 + tile_c(2 * jp) + tsel * 16 + csel;
@@ -1000,7 +1066,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
         const char* resb = (const char*)p.residual;
         char* outb = (char*)p.out + obatch * (int64_t)esz;
         const uint32_t rrow = (uint32_t)mrow * ldr_b, orow = (uint32_t)mrow * ldo_b;
-        const bool rb_row = has_rb && !rb_uni;               // row-group bias that changes inside the block (rare)
+        const bool rb_row = has_rb && !rb_in_acc;            // row-group bias that changes inside the block (rare)
         // Full-line stores (round 3).  A wave's first four 16-column tiles are 64 consecutive columns = one 128-B line of
         // fp16 per row, but after the pair swap a store instruction covers 16 rows x 64 B (4 lanes per row): half lines.
         // Measured with the same block tiles and nothing but the stores (tools/exp_store_pattern.py, 268 MB): 4.8 TB/s with
@@ -1245,9 +1311,12 @@ inline int gemm2_cu_count() {           // per device: partitions of one node ma
   return n[dev];
 }
 
+static thread_local bool g_gemm2_dry_run = false;   // anip_gemm2_would_take: walk the dispatch, launch nothing
+
 template <int BM2, int BN, int NW, int WNW, int BKT, int NST, bool CONV, bool TRANS, int SCHED = 0>
 int launch_gemm2(const anip_gemm_params& p, hipStream_t stream, int splitk = 1) {
   constexpr int NT2 = NW * 64;
+  if (g_gemm2_dry_run) return 1;
   constexpr int LDS = NST * (BM2 + BN) * BKT * 2;
   static bool attr_done_dev[16] = {};   // the attribute is per device
   bool& attr_done = attr_done_dev[gemm2_device()];
@@ -1360,6 +1429,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // split factor for problems with too few tiles to fill the chip (1 = no split); *cfg = tile configuration:
 // 128 / 160: 128-row 4-wave tiles of that width; 256 / 320: the wide 256-row tiles of that width
 static int gemm2_split(const anip_gemm_params& p, int* cfg) {
+  if (p.ln_stats != nullptr) return 1;     // the reduce pass does not carry the LayerNorm fold
   if (p.batch > 1 || p.act == 1 || p.trans_out || p.M < 1024 || p.M > 16384 || (p.N & 3) != 0) return 1;
   if (p.conv ? (p.Cin % 32 != 0) : (p.A2 != nullptr && (p.K1 % 32) != 0)) return 1;
   if ((((uintptr_t)p.bias | (uintptr_t)p.rowbias) & 15) != 0) return 1;
@@ -1409,7 +1479,17 @@ int64_t anip_gemm2_workspace_bytes(const anip_gemm_params& p) {
 }
 
 // split-K path: 1 if launched (partials + reduce), 0 if the problem is not split, < 0 on error
+int anip_gemm2_try(const anip_gemm_params& p, hipStream_t stream);
+// 1 if anip_gemm2_try would run p (the kernel family that carries the LayerNorm fold), without launching anything
+int anip_gemm2_would_take(const anip_gemm_params& p) {
+  g_gemm2_dry_run = true;
+  const int r = anip_gemm2_try(p, nullptr);
+  g_gemm2_dry_run = false;
+  return r == 1;
+}
+
 int anip_gemm2_try_splitk(const anip_gemm_params& p, hipStream_t stream) {
+  if (p.ln_stats != nullptr) return 0;      // the split-K reduce pass does not carry the LayerNorm fold
   int bn = 128;
   const int S = gemm2_split(p, &bn);
   if (S <= 1) return 0;

@@ -360,6 +360,61 @@ __global__ __launch_bounds__(NT) void layernorm_kernel(const f16* __restrict__ x
   }
 }
 
+// (mean, rstd) of every row: the statistics half of layernorm_kernel, for the LayerNorm fold of anip_gemm
+template <int G, int NCH>
+__global__ __launch_bounds__(NT) void row_stats_kernel(const f16* __restrict__ x, int64_t ld, float2* __restrict__ stats, int64_t M,
+                                                      int C, float eps) {
+  constexpr int RPB = NT / G;
+  const int gl = threadIdx.x % G;
+  const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / G;
+  const bool rvalid = row < M;
+  const int CV = C >> 3;
+  const f16* xr = x + (rvalid ? row : 0) * ld;
+  float v[NCH][8];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int cv = gl + G * k;
+    U4H8 t;
+    t.u = u32x4{0u, 0u, 0u, 0u};
+    if (rvalid && cv < CV) t.u = *(const u32x4*)(xr + cv * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      v[k][e] = (float)t.e[e];
+      s += v[k][e];
+    }
+  }
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / (float)C;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int cv = gl + G * k;
+    if (cv < CV) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = v[k][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = G / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  if (rvalid && gl == 0) stats[row] = make_float2(mean, rsqrtf(q / (float)C + eps));
+}
+
+template <int G>
+void launch_row_stats(int nch, dim3 grid, hipStream_t st, const f16* x, int64_t ld, float2* stats, int64_t M, int C, float eps) {
+  switch (nch) {
+    case 1: hipLaunchKernelGGL((row_stats_kernel<G, 1>), grid, dim3(NT), 0, st, x, ld, stats, M, C, eps); break;
+    case 2: hipLaunchKernelGGL((row_stats_kernel<G, 2>), grid, dim3(NT), 0, st, x, ld, stats, M, C, eps); break;
+    case 3: hipLaunchKernelGGL((row_stats_kernel<G, 3>), grid, dim3(NT), 0, st, x, ld, stats, M, C, eps); break;
+    case 4: hipLaunchKernelGGL((row_stats_kernel<G, 4>), grid, dim3(NT), 0, st, x, ld, stats, M, C, eps); break;
+    default: hipLaunchKernelGGL((row_stats_kernel<G, 5>), grid, dim3(NT), 0, st, x, ld, stats, M, C, eps); break;
+  }
+}
+
 template <int G>
 void launch_layernorm(int nch, dim3 grid, hipStream_t st, const f16* x, const float* gamma, const float* beta, f16* y,
                       int64_t M, int C, float eps, const float* pe, int64_t rpf, int F) {
@@ -522,6 +577,30 @@ extern "C" int anip_layernorm(const void* x, const float* gamma, const float* be
     }
   }
   ANIP_LAUNCH_CHECK("anip_layernorm");
+  return 0;
+}
+
+extern "C" int anip_row_stats(const void* x, int64_t ld, float* stats, int64_t M, int C, float eps, void* stream) {
+  ANIP_REQUIRE(x && stats, "anip_row_stats: null pointer");
+  ANIP_REQUIRE(M > 0 && C > 0 && (C & 7) == 0 && C <= LN_MAXCH * 512 && ld >= C && (ld & 7) == 0,
+               "anip_row_stats: bad C=%d / ld=%lld (multiples of 8, C <= %d)", C, (long long)ld, LN_MAXCH * 512);
+  ANIP_REQUIRE((((uintptr_t)x) & 15) == 0 && (((uintptr_t)stats) & 7) == 0, "anip_row_stats: misaligned pointers");
+  const int CV = C / 8;
+  int G = 8;
+  while (G < 64 && (CV + G - 1) / G > LN_MAXCH) G <<= 1;
+  const int nch = (CV + G - 1) / G;
+  const dim3 grid((unsigned)cdiv64(M, NT / G));
+  {
+    AnipProfScope prof_(ANIP_K_LAYERNORM, (void*)stream);
+    hipStream_t st = (hipStream_t)stream;
+    switch (G) {
+      case 8: launch_row_stats<8>(nch, grid, st, (const f16*)x, ld, (float2*)stats, M, C, eps); break;
+      case 16: launch_row_stats<16>(nch, grid, st, (const f16*)x, ld, (float2*)stats, M, C, eps); break;
+      case 32: launch_row_stats<32>(nch, grid, st, (const f16*)x, ld, (float2*)stats, M, C, eps); break;
+      default: launch_row_stats<64>(nch, grid, st, (const f16*)x, ld, (float2*)stats, M, C, eps); break;
+    }
+  }
+  ANIP_LAUNCH_CHECK("anip_row_stats");
   return 0;
 }
 

@@ -124,6 +124,24 @@ class PackedNet:
             self.t[k] = ops.pack_geglu(w, b)
         return self.t[k]
 
+    def ln_lin(self, wnames, bname, norm, alpha=1.0, geglu=False):
+        """nn.LayerNorm `norm` folded into the Linear it feeds (ops.fold_layernorm): (W gamma fp16, column sums fp32, beta W^T +
+        bias fp32), the weights being the row-concatenation of `wnames` (the temporal attention's [to_q; to_k; to_v])"""
+        k = ("lnlin", tuple(wnames), bname, norm, float(alpha), bool(geglu))
+        if k not in self.t:
+            W = torch.cat([self._raw(n).to(self.device, F32).reshape(self.sd[n].shape[0], -1) for n in wnames], dim=0)
+            b = self._raw(bname).to(self.device, F32) if bname is not None else None
+            self.t[k] = ops.fold_layernorm(W, b, self.f32(norm + ".weight"), self.f32(norm + ".bias"), alpha=alpha, geglu=geglu)
+        return self.t[k]
+
+    def pe_rowbias(self, pe_name, wnames, C, b, f):
+        """(LN(x) + pe[frame]) W^T = LN(x) W^T + pe[frame] W^T: the second term as a row-group bias table fp32 [b f][N]"""
+        k = ("perb", pe_name, tuple(wnames), int(b), int(f))
+        if k not in self.t:
+            W = torch.cat([self._raw(n).to(self.device, F16) for n in wnames], dim=0).float()
+            self.t[k] = (self.pe(pe_name, C)[:f] @ W.t()).repeat(b, 1).contiguous()
+        return self.t[k]
+
     def pe(self, name, C):
         """positional-encoding table fp32 [max_len][C]"""
         k = ("pe", name)
@@ -195,13 +213,36 @@ def resnet(net, p, x, skip, temb_rb, rows_per_group, eps, groups=32, gn_frames=1
 _FUSED_FFN = os.environ.get("ANIP_FUSED_FFN", "1") == "1"
 
 
-def feed_forward(net, p, n_in, residual):
-    """diffusers FeedForward(geglu) + residual: GEGLU fused in the first GEMM's epilogue."""
+# nn.LayerNorm folded into the GEMM it feeds (anip_gemm_params.ln_stats): the consumer reads the raw rows, gamma sits in its
+# weights and the mean / rstd correction is applied to its accumulators — the normalised tensor (84 MB at the 64x64 level)
+# is neither written nor read, one statistics pass over the rows replaces the LayerNorm kernel.  ANIP_LN_FOLD=0: LayerNorm
+# kernels (A/B measurements).
+_LN_FOLD = os.environ.get("ANIP_LN_FOLD", "1") == "1"
+_ln_ok_cache = {}
+
+
+def _ln_ok(M, N, K, **kw):
+    key = (M, N, K, tuple(sorted(kw.items())))
+    if key not in _ln_ok_cache:
+        _ln_ok_cache[key] = _LN_FOLD and ops.gemm_supports_ln(M, N, K, **kw)
+    return _ln_ok_cache[key]
+
+
+def feed_forward(net, p, h, norm):
+    """LayerNorm `norm` -> diffusers FeedForward(geglu) -> + h (src/models/attention.py:361,436-445,
+    src/models/motion_module.py:233-234,256-257): GEGLU fused in the first GEMM's epilogue."""
+    M, C = h.shape
+    fused = _FUSED_FFN and C == 320 and net.has(p + ".net.2.bias")
+    if not fused and _ln_ok(M, 8 * C, C, act=1):
+        wp, cs, bp = net.ln_lin((p + ".net.0.proj.weight",), p + ".net.0.proj.bias", norm, geglu=True)
+        g = ops.gemm(h, wp, bp, act=1, ln=(ops.row_stats(h), cs))
+        return ops.gemm(g, net.lin(p + ".net.2.weight"), net.f32(p + ".net.2.bias"), residual=h)
+    n_in = ops.layernorm(h, net.f32(norm + ".weight"), net.f32(norm + ".bias"))
     wp, bp = net.geglu(p + ".net.0.proj")
-    if _FUSED_FFN and n_in.shape[1] == 320 and net.has(p + ".net.2.bias"):
-        return ops.ffn_geglu(n_in, wp, bp, net.lin(p + ".net.2.weight"), net.f32(p + ".net.2.bias"), residual)
+    if fused:
+        return ops.ffn_geglu(n_in, wp, bp, net.lin(p + ".net.2.weight"), net.f32(p + ".net.2.bias"), h)
     g = ops.gemm(n_in, wp, bp, act=1)
-    return ops.gemm(g, net.lin(p + ".net.2.weight"), net.f32(p + ".net.2.bias"), residual=residual)
+    return ops.gemm(g, net.lin(p + ".net.2.weight"), net.f32(p + ".net.2.bias"), residual=h)
 
 
 class RefState:
@@ -265,21 +306,32 @@ def transformer_block(net, p, h, Nf, T, heads, attn2_vec, rows_per_sample, ref=N
     (src/models/attention.py:383-445, src/models/mutual_self_attention.py:93-265).  h (Nf*T, C)."""
     C = h.shape[1]
     d = C // heads
-    nh = ops.layernorm(h, net.f32(p + ".norm1.weight"), net.f32(p + ".norm1.bias"))
+    M = h.shape[0]
     mode = ref.mode if ref is not None else "plain"
-    if mode == "write":
-        ref.written = nh.reshape(Nf, T, C)
-        if stop_after_bank:
-            return None
-    # Q token-major; K HEAD-MAJOR (heads, tokens, d): with a fused [to_q; to_k] projection every head's K row (2 d
-    # bytes) sits at a 4C-byte stride and the attention kernel's K-tile reads touch 2-3x the cache lines; head-major, a
-    # 64-key tile of a head is one contiguous run (measured at 64x64, d = 40: 1.75 ms fused rows, 1.60 ms separate
-    # matrices, 1.54 ms contiguous rows — against +12 us for the second GEMM launch)
-    # Q leaves its projection multiplied by d^-1/2 log2(e) (the GEMM's alpha: still one fp16 rounding of the fp32 accumulator):
-    # the attention kernel then exponentiates q.k in base 2 with no per-score multiply (anip_ref_attention_ex)
-    q = ops.gemm(nh, net.lin(p + ".attn1.to_q.weight"), alpha=ops.attn_q_alpha(d))
-    k = ops.gemm(nh, net.lin(p + ".attn1.to_k.weight"), head_dim=d)
-    vt = ops.gemm(nh, net.lin(p + ".attn1.to_v.weight"), trans_out=True)  # V^T [C][Nf*T]
+    qa = ops.attn_q_alpha(d)
+    # Q token-major, multiplied by d^-1/2 log2(e) in its projection (the GEMM's alpha: still one fp16 rounding of the fp32
+    # accumulator; the attention kernel then exponentiates q.k in base 2 with no per-score multiply); K HEAD-MAJOR (heads,
+    # tokens, d): with a fused [to_q; to_k] projection every head's K row (2 d bytes) sits at a 4C-byte stride and the
+    # attention kernel's K-tile reads touch 2-3x the cache lines (measured at 64x64, d = 40: 1.75 ms fused rows, 1.60 ms
+    # separate matrices, 1.54 ms contiguous rows — against +12 us for the second GEMM launch); V transposed [C][Nf*T]
+    wq, wk, wv = p + ".attn1.to_q.weight", p + ".attn1.to_k.weight", p + ".attn1.to_v.weight"
+    if mode != "write" and _ln_ok(M, C, C) and _ln_ok(M, C, C, head_dim=d) and _ln_ok(M, C, C, trans_out=True):
+        st = ops.row_stats(h)                       # norm1 folded into the three projections
+        Wq, sq, bq = net.ln_lin((wq,), None, p + ".norm1", alpha=qa)
+        Wk, sk, bk = net.ln_lin((wk,), None, p + ".norm1")
+        Wv, sv, bv = net.ln_lin((wv,), None, p + ".norm1")
+        q = ops.gemm(h, Wq, bq, alpha=qa, ln=(st, sq))
+        k = ops.gemm(h, Wk, bk, head_dim=d, ln=(st, sk))
+        vt = ops.gemm(h, Wv, bv, trans_out=True, ln=(st, sv))
+    else:
+        nh = ops.layernorm(h, net.f32(p + ".norm1.weight"), net.f32(p + ".norm1.bias"))
+        if mode == "write":
+            ref.written = nh.reshape(Nf, T, C)
+            if stop_after_bank:
+                return None
+        q = ops.gemm(nh, net.lin(wq), alpha=qa)
+        k = ops.gemm(nh, net.lin(wk), head_dim=d)
+        vt = ops.gemm(nh, net.lin(wv), trans_out=True)  # V^T [C][Nf*T]
     kw = {}
     if mode == "read" and ref.bank is not None:
         if ref.kref is None or ref.stale:
@@ -291,8 +343,7 @@ def transformer_block(net, p, h, Nf, T, heads, attn2_vec, rows_per_sample, ref=N
     # attn1 out-proj + residual (+ the collapsed attn2: one vector per sample)
     h = ops.gemm(a, net.lin(p + ".attn1.to_out.0.weight"), net.f32(p + ".attn1.to_out.0.bias"),
                  rowbias=attn2_vec, rows_per_group=rows_per_sample, residual=h)
-    n3 = ops.layernorm(h, net.f32(p + ".norm3.weight"), net.f32(p + ".norm3.bias"))
-    return feed_forward(net, p + ".ff", n3, h)
+    return feed_forward(net, p + ".ff", h, p + ".norm3")
 
 
 def spatial_transformer(net, p, x, heads, attn2_vec, frames_per_sample, ref=None, ref_index=None,
@@ -328,14 +379,20 @@ def motion_module(net, p, x, b, f, heads):
             raise ValueError(f"video_length {f} exceeds temporal_position_encoding_max_len {pe.shape[0]}")
         # LN + positional encoding of the frame (added to the attention INPUT: q, k and v see it; the
         # residual below uses the un-encoded h — src/models/motion_module.py:244-254,365-366)
-        nh = ops.layernorm(h, net.f32(bp + f".norms.{i}.weight"), net.f32(bp + f".norms.{i}.bias"), pe=pe,
-                           rows_per_frame=T, frames=f)
-        qkv = ops.gemm(nh, net.cat_lin((ap + ".to_q.weight", ap + ".to_k.weight", ap + ".to_v.weight")))
+        wn = (ap + ".to_q.weight", ap + ".to_k.weight", ap + ".to_v.weight")
+        if _ln_ok(N * T, 3 * C, C):
+            # folded: (LN(h) + pe_f) W^T = rstd (h W'^T - mean s) + beta W^T + pe_f W^T, the last term a per-frame row bias
+            Wf, cs, bf = net.ln_lin(wn, None, bp + f".norms.{i}")
+            rb = net.pe_rowbias(pe_name, wn, C, b, f) if pe is not None else None
+            qkv = ops.gemm(h, Wf, bf, rowbias=rb, rows_per_group=T if rb is not None else 0, ln=(ops.row_stats(h), cs))
+        else:
+            nh = ops.layernorm(h, net.f32(bp + f".norms.{i}.weight"), net.f32(bp + f".norms.{i}.bias"), pe=pe,
+                               rows_per_frame=T, frames=f)
+            qkv = ops.gemm(nh, net.cat_lin(wn))
         a = ops.temporal_attention(qkv, b, f, T, heads, d)
         h = ops.gemm(a, net.lin(ap + ".to_out.0.weight"), net.f32(ap + ".to_out.0.bias"), residual=h)
         i += 1
-    n = ops.layernorm(h, net.f32(bp + ".ff_norm.weight"), net.f32(bp + ".ff_norm.bias"))
-    h = feed_forward(net, bp + ".ff", n, h)
+    h = feed_forward(net, bp + ".ff", h, bp + ".ff_norm")
     out = ops.gemm(h, net.lin(p + ".proj_out.weight"), net.f32(p + ".proj_out.bias"), residual=x.reshape(N * T, C))
     return out.reshape(N, H, W, C)
 

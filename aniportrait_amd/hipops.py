@@ -276,7 +276,7 @@ def layernorm(x, gamma, beta, eps=1e-5, pe=None, rows_per_frame=0, frames=0):
 
 
 def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None, act=0, out_f32=False,
-         alpha=1.0, out=None, conv=None, batch=1, ldo=None, ldr=None, trans_out=False, head_dim=0, debug_ws=None):
+         alpha=1.0, out=None, conv=None, batch=1, ldo=None, ldr=None, trans_out=False, head_dim=0, debug_ws=None, ln=None):
     """out = epilogue(alpha * A @ W^T).
 
     A (M, K) fp16 [+ A2 (M, K2): K split over two sources]; W (N, K) fp16; bias (N,) fp32;
@@ -287,6 +287,8 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
     batch > 1: A (B, M, K) or (M, K) shared; W (B, N, K) or (N, K) shared -> out (B, M, N).
     trans_out: return the transposed result (N, M) (bias only, fp16).
     head_dim > 0: head-major result (N / head_dim, M, head_dim): each head's rows contiguous (K of ref_attention).
+    ln=(stats, colsum): LayerNorm folded in (anip_gemm_params.ln_stats): A = the raw rows, W = fold_layernorm's weights,
+    stats = row_stats(A), colsum = fold_layernorm's column sums, bias = its folded bias.
     """
     lib = L.load()
     p = L.GemmParams()
@@ -356,6 +358,12 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
             raise TypeError("residual: expected fp16")
         p.residual, p.ldr = _p(residual), int(ldr if ldr is not None else n_out)
     p.act = int(act)
+    if ln is not None:
+        stats, colsum = ln
+        _req(stats, F32, "ln stats")
+        _req(colsum, F32, "ln colsum")
+        assert stats.numel() == 2 * M and colsum.numel() == N and conv is None and A2 is None and not batched
+        p.ln_stats, p.ln_colsum = _p(stats), _p(colsum)
     if _WORK is not None:
         if conv is not None:
             desc = (f"N{conv['Nimg']} {conv['Hin']}x{conv['Win']} Cin{conv['Cin']} Cout{N} s{conv['stride']}"
@@ -365,7 +373,7 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
             desc = (f"M{M} N{N} K{K}{' b%d' % batch if batched else ''}{' geglu' if act == 1 else ''}"
                     f"{' A2' if A2 is not None else ''}{' rb' if rowbias is not None else ''}"
                     f"{' res' if residual is not None else ''}{' T' if trans_out else ''}{' f32' if out_f32 else ''}"
-                    f"{' hm' if head_dim else ''}")
+                    f"{' hm' if head_dim else ''}{' ln' if ln is not None else ''}")
         nb = max(1, int(p.batch))
         a_bytes = (conv["Nimg"] * conv["Hin"] * conv["Win"] * conv["Cin"] if conv is not None else
                    M * K * (nb if (not batched or A.dim() == 3) else 1)) * 2
@@ -381,6 +389,45 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
         p.workspace, p.workspace_bytes = _p(debug_ws), debug_ws.numel() * debug_ws.element_size()
     L.check(lib.anip_gemm(C.byref(p), _stream()), "anip_gemm")
     return out
+
+
+def row_stats(x, eps=1e-5):
+    """(mean, rstd) fp32 pairs of the rows of x (M, C) fp16: the statistics of nn.LayerNorm(C, eps) for gemm(ln=...)"""
+    lib = L.load()
+    _req(x, F16, "x")
+    M, Cc = x.shape
+    stats = torch.empty((M, 2), dtype=F32, device=x.device)
+    _work(K_LAYERNORM, M * Cc * 2, f"row_stats M{M} C{Cc}")
+    L.check(lib.anip_row_stats(_p(x), x.stride(0), _p(stats), M, Cc, float(eps), _stream()), "anip_row_stats")
+    return stats
+
+
+def gemm_supports_ln(M, N, K, act=0, trans_out=False, head_dim=0, lda=None, ldw=None):
+    """whether gemm(ln=...) of this shape runs on the kernel that carries the LayerNorm fold (anip_gemm_supports_ln)"""
+    lib = L.load()
+    p = L.GemmParams()
+    p.M, p.N, p.K, p.batch, p.act = int(M), int(N), int(K), 1, int(act)
+    p.lda, p.ldw = int(lda if lda is not None else K), int(ldw if ldw is not None else K)
+    p.trans_out, p.head_dim, p.alpha = int(bool(trans_out)), int(head_dim), 1.0
+    return bool(lib.anip_gemm_supports_ln(C.byref(p)))
+
+
+def fold_layernorm(W, bias, gamma, beta, alpha=1.0, geglu=False):
+    """weights of `LayerNorm(gamma, beta) -> Linear(W, bias)` for gemm(ln=...): (W' = W gamma  fp16, colsum = alpha sum_k W'
+    fp32, bias' = alpha (W beta + bias) fp32).  W (N, K) fp16 / fp32, gamma / beta (K,) fp32.  alpha: the GEMM's alpha
+    (the kernel multiplies the accumulators by it; the additive terms carry it here).  geglu: pack W' / the vectors with
+    pack_geglu afterwards (rows per 32 as [16 value | 16 gate])."""
+    Wf = W.float() * gamma.float()[None, :]
+    Wh = Wf.half()
+    colsum = Wh.float().sum(dim=1) * alpha
+    b = W.float() @ beta.float()
+    if bias is not None:
+        b = b + bias.float()
+    b = b * alpha
+    if geglu:
+        _, colsum = pack_geglu(Wh, colsum)
+        Wh, b = pack_geglu(Wh, b)
+    return Wh.contiguous(), colsum.contiguous().float(), b.contiguous().float()
 
 
 def ffn_geglu(x, w1p, b1p, w2, b2, residual=None):

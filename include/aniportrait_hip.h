@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ANIP_ABI_VERSION 12
+#define ANIP_ABI_VERSION 13
 
 int anip_version(void);
 const char* anip_last_error(void);
@@ -103,9 +103,21 @@ typedef struct anip_gemm_params {
    * The K projection of anip_ref_attention (to_k of src/models/mutual_self_attention.py:147-165): a 64-key tile of one
    * head is then one contiguous run instead of 2 d-byte pieces at a C-byte stride. */
   int head_dim;
+  /* LayerNorm folded into the GEMM (ln_stats != NULL): A holds the RAW rows x, W the weights multiplied by the norm's gamma
+   * (W'[n][k] = W[n][k] gamma[k], fp16), ln_stats = (mean, rstd) fp32 per row of A (anip_row_stats), ln_colsum[n] =
+   * sum_k W'[n][k] fp32, and `bias` = beta W^T + b.  The kernel applies out = rstd (alpha acc - alpha mean colsum) + bias
+   * to its finished accumulators: nn.LayerNorm -> nn.Linear (src/models/attention.py:331-362, src/models/motion_module.py:
+   * 228-234) without the normalised tensor ever being written or read.  Any epilogue (bias, row-group bias, residual,
+   * GEGLU, transposed / head-major output); plain single-source A, batch 1, no split-K: anip_gemm_supports_ln(p) tells
+   * whether a problem qualifies (the caller otherwise runs anip_layernorm + anip_gemm). */
+  const float* ln_stats; const float* ln_colsum;
 } anip_gemm_params;
 int64_t anip_gemm_workspace_bytes(const anip_gemm_params* p);
 int anip_gemm(const anip_gemm_params* p, void* stream);
+int anip_gemm_supports_ln(const anip_gemm_params* p);
+/* (mean, rstd) fp32 pairs of the rows of x [M][ld] fp16 over C channels (C % 8 == 0): the statistics of nn.LayerNorm(C, eps),
+ * two-pass in registers like anip_layernorm — the input of the LayerNorm fold of anip_gemm. */
+int anip_row_stats(const void* x, int64_t ld, float* stats, int64_t M, int C, float eps, void* stream);
 
 /* ---- fused GEGLU feed-forward (the engine's default at C = 320; ANIP_FUSED_FFN=0 selects two anip_gemm calls) -------
  * out[M][C] = residual + b2 + W2 · ((x W1v^T + b1v) * gelu_erf(x W1g^T + b1g)):  diffusers FeedForward("geglu") of

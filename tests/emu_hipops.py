@@ -41,7 +41,7 @@ def _geglu_unpack(y):
 
 
 def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None, act=0, out_f32=False,
-         alpha=1.0, out=None, conv=None, batch=1, ldo=None, ldr=None, trans_out=False, head_dim=0):
+         alpha=1.0, out=None, conv=None, batch=1, ldo=None, ldr=None, trans_out=False, head_dim=0, ln=None):
     assert A.dtype == F16 and W.dtype == F16
     if A.dim() == 3 or W.dim() == 3:
         y = alpha * torch.matmul(A.float(), W.float().transpose(-1, -2))
@@ -67,6 +67,9 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
     else:
         a = A.float() if A2 is None else torch.cat([A.float(), A2.float()], dim=1)
         y = alpha * (a @ W.float().t())
+        if ln is not None:      # LayerNorm fold: rstd (alpha acc - mean colsum) with colsum (and bias) already carrying alpha
+            stats, colsum = ln
+            y = stats[:, 1:2] * (y - stats[:, 0:1] * colsum.float()[None, :])
     M, N = y.shape
     if bias is not None:
         y = y + bias.float()
@@ -87,6 +90,17 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
         out.copy_(y.reshape(out.shape))
         return out
     return y
+
+
+def row_stats(x, eps=1e-5):
+    xf = x.float()
+    mean = xf.mean(dim=1)
+    var = (xf - mean[:, None]).pow(2).mean(dim=1)
+    return torch.stack([mean, torch.rsqrt(var + eps)], dim=1).contiguous()
+
+
+def gemm_supports_ln(M, N, K, act=0, trans_out=False, head_dim=0, lda=None, ldw=None):
+    return True       # the emulation has one GEMM: every shape takes the folded form (the engine's other branch is the old path)
 
 
 def ffn_geglu(x, w1p, b1p, w2, b2, residual=None):
@@ -248,7 +262,7 @@ def f16_to_u8(src, scale=1.0, shift=0.0):
     return ((src.float() * scale + shift).clamp(0, 1).to(F16).float() * 255.0).to(torch.uint8)
 
 
-_EMULATED = ("groupnorm", "layernorm", "gemm", "ffn_geglu", "conv3x3", "conv_small", "conv_direct", "batchnorm", "ref_attention",
+_EMULATED = ("groupnorm", "layernorm", "gemm", "row_stats", "gemm_supports_ln", "ffn_geglu", "conv3x3", "conv_small", "conv_direct", "batchnorm", "ref_attention",
              "temporal_attention", "softmax_rows", "linear_small", "add", "window_accumulate", "cfg_ddim_step",
              "ncfhw_to_nhwc", "nhwc_to_ncfhw", "u8_to_f16", "f16_to_u8")
 

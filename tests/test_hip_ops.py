@@ -251,6 +251,62 @@ def test_softmax_rows():
     close(ops.softmax_rows(s), torch.softmax(s, -1), "softmax rows 100", rtol=2e-3, arms=1e-2)
 
 
+@pytest.mark.parametrize("case", ["bias", "residual", "head_major", "trans", "geglu", "rowbias", "ragged", "alpha", "wide1280"])
+def test_gemm_layernorm_fold(case):
+    """anip_gemm_params.ln_stats: LayerNorm folded into the consuming GEMM — raw rows in, gamma inside the weights, the
+    rank-one mean correction and rstd applied to the accumulators — against LayerNorm -> Linear in fp32, in every
+    epilogue form the engine uses it with (attention.py:331-362, motion_module.py:228-234)"""
+    ops = _ops()
+    M, K, N, kw, act = 8192, 320, 320, {}, 0
+    if case == "geglu":
+        K, N, act = 640, 5120, 1
+    if case == "rowbias":
+        N = 960
+    if case == "ragged":
+        M = 33003
+    if case == "wide1280":
+        M, K, N = 2048, 1280, 3840
+    x = (rnd(M, K, seed=400, scale=1.5).float() + 0.7 * rnd(M, 1, seed=401).float()).half().to(DEV)   # rows with their own means
+    W = rnd(N, K, seed=402, scale=K ** -0.5).to(DEV)
+    b = rnd(N, seed=403).float().to(DEV)
+    gamma = (1.0 + 0.3 * rnd(K, seed=404).float()).to(DEV)
+    beta = (0.2 * rnd(K, seed=405).float()).to(DEV)
+    alpha = 0.228 if case == "alpha" else 1.0
+    ref = alpha * (torch.nn.functional.layer_norm(x.float(), (K,), gamma, beta, 1e-5) @ W.float().t() + b)
+    if case == "residual":
+        kw["residual"] = rnd(M, N, seed=406).to(DEV)
+        ref = ref + kw["residual"].float()
+    if case == "rowbias":
+        kw["rowbias"], kw["rows_per_group"] = rnd(M // 256, N, seed=407).float().to(DEV), 256
+        ref = ref + kw["rowbias"].repeat_interleave(256, dim=0)
+    if case == "head_major":
+        kw["head_dim"] = 40
+    if case == "trans":
+        kw["trans_out"] = True
+    if act == 1:
+        ref = ref[:, : N // 2] * torch.nn.functional.gelu(ref[:, N // 2:])
+    assert ops.gemm_supports_ln(M, N, K, act=act, trans_out=case == "trans", head_dim=kw.get("head_dim", 0))
+    Wf, colsum, bf = ops.fold_layernorm(W, b, gamma, beta, alpha=alpha, geglu=act == 1)
+    got = ops.gemm(x, Wf, bf, act=act, alpha=alpha, ln=(ops.row_stats(x, 1e-5), colsum), **kw)
+    if case == "head_major":
+        got = got.permute(1, 0, 2).reshape(M, N)
+    if case == "trans":
+        got = got.t()
+    close(got, ref, f"gemm LN fold {case}", rtol=6e-3, arms=6e-3)
+    # and no worse than the two-kernel form it replaces
+    if case in ("bias", "residual"):
+        two = ops.gemm(ops.layernorm(x, gamma, beta, 1e-5), W, b, **kw)
+        e_fold = float((got.float() - ref).pow(2).mean().sqrt())
+        e_two = float((two.float() - ref).pow(2).mean().sqrt())
+        assert e_fold <= 1.5 * e_two + 1e-4, (e_fold, e_two)
+
+
+def test_gemm_layernorm_fold_not_supported_shapes():
+    ops = _ops()
+    assert not ops.gemm_supports_ln(100, 320, 320)        # the small-problem kernel does not carry the fold
+    assert ops.gemm_supports_ln(2048, 1280, 1280)
+
+
 # ------------------------------------------------------------------------------------------------
 # attention
 # ------------------------------------------------------------------------------------------------

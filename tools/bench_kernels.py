@@ -53,6 +53,9 @@ def timeit(fn, iters=10, warmup=3):
 
 
 def r16(*shape, scale=1.0):
+    import os
+    if os.environ.get("OPERANDS_ZERO"):   # all-zero operands: same instruction stream, no data toggling (clock / power check)
+        return torch.zeros(shape, device=DEV, dtype=torch.float16)
     return (torch.randn(shape, device=DEV) * scale).half()
 
 
