@@ -74,7 +74,7 @@ __device__ __forceinline__ void row_swap(float& x, float& y) {
 //     flop drops by 1/4..1/3 and every DMA row is a full 128-B line (BK = 32 rows are half lines), which is what
 //     bounds the smaller tiles (measured: DMA alone = 0.93 ms of the 1.18 ms 8192^3 GEMM).
 //   SCHED = 1 (wide tiles only): the quarter-phased main loop (round 3), see "quarter-phased schedule" below.
-template <int BM2, int BN, int NW, int WNW, int BKT, int NST, bool CONV, bool TRANS, int SCHED = 0>
+template <int BM2, int BN, int NW, int WNW, int BKT, int NST, bool CONV, bool TRANS, int SCHED = 0, bool LNF = false>
 __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void gemm2_kernel(const anip_gemm_params p,
                                                                                            const int dbg, const int splitk) {
   constexpr int NT2 = NW * 64;
@@ -525,7 +525,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
     // start the accumulators from the per-column additive terms (bias and, when the block's rows share one row group,
     // the row-group bias): NB small L2-resident loads that travel with the prologue DMA, no registers, and nothing
     // left to fetch for them in the epilogue, where loads queue behind the tile's stores (see there).
-    const bool acc_has_bias = !TRANS && !(dbg & 8) && splitk <= 1 && p.alpha == 1.0f && p.ln_stats == nullptr && m0 + BM2 <= p.M && n0 + BN <= p.N &&
+    const bool acc_has_bias = !TRANS && !(dbg & 8) && splitk <= 1 && p.alpha == 1.0f && !LNF && m0 + BM2 <= p.M && n0 + BN <= p.N &&
                               (p.bias != nullptr || p.rowbias != nullptr) &&
                               (p.rowbias == nullptr || (((p.ld_rowbias & 3) == 0) && ((((uintptr_t)p.rowbias) & 15) == 0)));
     const bool rb_uni = acc_has_bias && p.rowbias != nullptr &&
@@ -736,8 +736,8 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
     float alpha = p.alpha;
     // what the accumulators already carry of the per-column additive terms (see acc_has_bias above, and the fold below)
     bool bias_in_acc = acc_has_bias, rb_in_acc = rb_uni;
-    if (p.ln_stats != nullptr) {
-      // LayerNorm folded into this GEMM (anip_gemm_params.ln_stats): A holds the RAW rows x, W carries gamma, and with
+    if constexpr (LNF) {
+      // LayerNorm folded into this GEMM (anip_gemm_params.ln_stats; its own instantiation: the plain kernels carry none of this): A holds the RAW rows x, W carries gamma, and with
       // (mean, rstd) of every row and s[n] = sum_k W[n][k]
       //     LN(x) W^T = rstd (x W^T - mean s)      [+ beta W^T + b, which the caller passes as `bias`]
       // is applied to the finished accumulators — the normalised tensor is never written or read.  Full tiles with 16-B
@@ -1313,7 +1313,7 @@ inline int gemm2_cu_count() {           // per device: partitions of one node ma
 
 static thread_local bool g_gemm2_dry_run = false;   // anip_gemm2_would_take: walk the dispatch, launch nothing
 
-template <int BM2, int BN, int NW, int WNW, int BKT, int NST, bool CONV, bool TRANS, int SCHED = 0>
+template <int BM2, int BN, int NW, int WNW, int BKT, int NST, bool CONV, bool TRANS, int SCHED = 0, bool LNF = false>
 int launch_gemm2(const anip_gemm_params& p, hipStream_t stream, int splitk = 1) {
   constexpr int NT2 = NW * 64;
   if (g_gemm2_dry_run) return 1;
@@ -1321,7 +1321,7 @@ int launch_gemm2(const anip_gemm_params& p, hipStream_t stream, int splitk = 1) 
   static bool attr_done_dev[16] = {};   // the attribute is per device
   bool& attr_done = attr_done_dev[gemm2_device()];
   if (!attr_done) {
-    auto kfn = gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS, SCHED>;
+    auto kfn = gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS, SCHED, LNF>;
     if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
       anip_set_error("anip_gemm: cannot raise the dynamic LDS limit to %d bytes", LDS);
       return -2;
@@ -1338,7 +1338,7 @@ int launch_gemm2(const anip_gemm_params& p, hipStream_t stream, int splitk = 1) 
     const unsigned ncu = (unsigned)gemm2_cu_count();
     if (ncu >= 8 && (ncu & 7) == 0 && grid > ncu) grid = ncu;
   }
-  hipLaunchKernelGGL((gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS, SCHED>), dim3(grid, (unsigned)p.batch, 1),
+  hipLaunchKernelGGL((gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS, SCHED, LNF>), dim3(grid, (unsigned)p.batch, 1),
                      dim3(NT2), LDS, stream, p, dbg, splitk);
   return 1;
 }
@@ -1365,11 +1365,17 @@ int dispatch_gemm2(const anip_gemm_params& p, hipStream_t stream, int splitk = 1
     }
 #endif
     if (gemm2_sched() == 1) {
+      if (p.ln_stats != nullptr && !p.conv)      // LayerNorm fold: its own instantiations
+        return p.trans_out ? launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, true, 1, true>(p, stream, splitk)
+                           : launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, false, 1, true>(p, stream, splitk);
       if (p.conv) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, true, false, 1>(p, stream, splitk);
       if (p.trans_out) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, true, 1>(p, stream, splitk);
       return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, false, 1>(p, stream, splitk);
     }
   }
+  if (p.ln_stats != nullptr && !p.conv)
+    return p.trans_out ? launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, true, 0, true>(p, stream, splitk)
+                       : launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, false, 0, true>(p, stream, splitk);
   if (p.conv) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, true, false>(p, stream, splitk);
   if (p.trans_out) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, true>(p, stream, splitk);
   return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, false>(p, stream, splitk);
@@ -1544,7 +1550,9 @@ int anip_gemm2_try(const anip_gemm_params& p, hipStream_t stream) {
   if (k64 && force != 1 && (p.K >= 640 || (p.K >= 256 && p.N >= 640) || force == 2)) {
     const int64_t pad320 = (int64_t)((p.N + 319) / 320) * 320, pad256 = (int64_t)((p.N + 255) / 256) * 256;
     int wbn = 0;
-    if (p.act == 1) wbn = (pad256 * 100 <= (int64_t)p.N * 115) ? 256 : 0;   // GEGLU pairs tiles: even count per wave
+    // (LayerNorm fold: the 256 x 256 and the 128-row instantiations take its accumulator transform without spilling; the
+    //  256 x 320 / 256 x 160 / 256 x 128 ones, already at their VGPR limit, spill 25-90 dwords in the epilogue and lose 45 %)
+    if (p.act == 1 || p.ln_stats != nullptr) wbn = (pad256 * 100 <= (int64_t)p.N * 115) ? 256 : 0;   // GEGLU pairs tiles: even count per wave
     else if (pad320 <= pad256 && pad320 * 100 <= (int64_t)p.N * 115) wbn = 320;
     else if (pad256 * 100 <= (int64_t)p.N * 115) wbn = 256;
     static const int wide_min = getenv("ANIP_GEMM2_WIDE_MIN") ? atoi(getenv("ANIP_GEMM2_WIDE_MIN")) : 192;   // experiments
@@ -1559,7 +1567,7 @@ int anip_gemm2_try(const anip_gemm_params& p, hipStream_t stream) {
   const int64_t tiles256 = mt256 * ((p.N + bn - 1) / bn) * nb;
   if (tiles256 * 2 < 128) return 0;
   static const int big_min = getenv("ANIP_GEMM2_BIG_MIN") ? atoi(getenv("ANIP_GEMM2_BIG_MIN")) : 1024;   // experiments
-  const bool big = tiles256 >= big_min;   // >= 2 full rounds of 2 x 256 resident 256-row blocks
+  const bool big = tiles256 >= big_min && p.ln_stats == nullptr;   // >= 2 full rounds of 2 x 256 resident 256-row blocks
   if (big) return bn == 128 ? dispatch_gemm2<256, 128, 8, 2, 32, 3>(p, stream) : dispatch_gemm2<256, 160, 8, 2, 32, 3>(p, stream);
   // At most one 128-row tile per CU (the 8x8 level, M = 2048): 64-deep K-tiles and EIGHT waves per tile (wave tile 32 x 64 /
   // 32 x 80).  These launches are bound by what one wave per SIMD can do in order — issue its share of the LDS-DMA, read its

@@ -215,9 +215,12 @@ _FUSED_FFN = os.environ.get("ANIP_FUSED_FFN", "1") == "1"
 
 # nn.LayerNorm folded into the GEMM it feeds (anip_gemm_params.ln_stats): the consumer reads the raw rows, gamma sits in its
 # weights and the mean / rstd correction is applied to its accumulators — the normalised tensor (84 MB at the 64x64 level)
-# is neither written nor read, one statistics pass over the rows replaces the LayerNorm kernel.  ANIP_LN_FOLD=0: LayerNorm
-# kernels (A/B measurements).
-_LN_FOLD = os.environ.get("ANIP_LN_FOLD", "1") == "1"
+# is neither written nor read, one statistics pass over the rows replaces the LayerNorm kernel.  Parity-green, and OFF:
+# measured on MI355X inside one call each (profiles/r04/n_*): the LayerNorm family drops 49 -> 29 ms per clip, but the consuming
+# GEMMs gain more than that (657 -> 695 ms: the temporal qkv projection at 64x64 128 -> 219 us, the C = 640 GEGLU 243 -> 265 us)
+# — their K = 320 .. 1280 main loops are short, and the extra dependent loads of the accumulator transform sit exposed in front
+# of the stores.  ANIP_LN_FOLD=1 selects it (A/B measurements, tests).
+_LN_FOLD = os.environ.get("ANIP_LN_FOLD", "0") == "1"
 _ln_ok_cache = {}
 
 
