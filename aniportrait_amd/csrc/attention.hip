@@ -513,6 +513,165 @@ __global__ __launch_bounds__(NT) void temporal_attn_kernel(const f16* __restrict
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// temporal attention on MFMA for the 16-frame windows every configuration of the path runs (F == 16, round 4).
+// temporal_attn_kernel above is VALU-bound (one v_dot2 per key pair and channel pair: 3.3 TB/s of 336 MB at the 64x64 level);
+// here a (pixel, head) problem is five to fifteen 16x16x32 MFMAs:
+//   S^T = K Q^T  (16 keys x 16 queries, contraction over d in ceil(d / 32) steps; lanes beyond d contribute zeros),
+//   softmax over the keys of a query = over the 4 accumulator registers and the 4 lane groups of a column,
+//   O^T = V^T P^T (d x 16 queries; the 16 keys occupy k-slot groups 0 and 2 of the 32: the probabilities reach the B layout by
+//   one v_permlane16_swap per dword, V^T is staged transposed — [channel][key] — with zeros read for the other two groups).
+// One block per (b, pixel, channel group of <= 320 channels) as before: q | k | v of the 16 frames staged with full-line loads
+// (V transposed on the way, frame pairs interleaved with v_perm), wave w takes heads w, w + 4, ..; the output tile goes back
+// through LDS so that every frame's row segment leaves in 16-B pieces.
+// ---------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(NT) void temporal_attn16_kernel(const f16* __restrict__ qkv, f16* __restrict__ out, int T, int heads,
+                                                            float scale_log2e, int hpg) {
+  constexpr int F = 16;
+  constexpr int DQ = (D + 31) / 32;          // contraction steps of K Q^T
+  constexpr int DT = (D + 15) / 16;          // 16-row tiles of O^T
+  constexpr int VS = 32;                     // bytes per V^T row: 16 keys = two 16-B halves, swapped in rows with bit 3 set (conflict-free b128 reads down 16 rows)
+  extern __shared__ __attribute__((aligned(16))) char tsm[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int C = heads * D, CG = hpg * D, ngroups = heads / hpg;
+  const int RS = CG * 2 + 16;                // bytes per q / k / o row (pad: conflict-free b128 reads down a column of rows)
+  const int g = blockIdx.x % ngroups;
+  const int64_t bt = blockIdx.x / ngroups;
+  const int t = (int)(bt % T);
+  const int64_t b = bt / T;
+  char* sq = tsm;
+  char* sk = sq + F * RS;
+  char* so = sq;                             // the output tile takes the place of q: head h's columns are read (q) and written (o) by
+                                             // the one wave that owns head h, after its S^T is complete
+  char* svt = sk + F * RS;                   // (CG + 16) rows: a head's last O^T tile may read up to 15 rows past its channels
+  const int cpr = CG >> 3;                   // 16-B chunks per (frame, q | k | v) segment
+  const int64_t fstride = (int64_t)T * 3 * C;
+  const int nqk = 2 * F * cpr, nv = (F / 2) * cpr;
+  constexpr int IQK = (2 * F * 40 + NT - 1) / NT, IV = ((F / 2) * 40 + NT - 1) / NT;   // register slots at the widest group (320 channels)
+  u32x4 rqk[IQK], rva[IV], rvb[IV];
+  auto issue_loads = [&](int t) {
+    const f16* base = qkv + ((b * F) * (int64_t)T + t) * (3 * (int64_t)C) + g * CG;
+#pragma unroll
+    for (int i = 0; i < IQK; ++i) {
+      const int it = tid + i * NT;
+      if (it < nqk) {
+        const int seg = it / (F * cpr), r = it - seg * (F * cpr);
+        const int f = r / cpr, c8 = r - f * cpr;
+        rqk[i] = *(const u32x4*)(base + f * fstride + seg * C + c8 * 8);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < IV; ++i) {
+      const int it = tid + i * NT;
+      if (it < nv) {
+        const int fp = it / cpr, c8 = it - fp * cpr;
+        rva[i] = *(const u32x4*)(base + (2 * fp) * fstride + 2 * C + c8 * 8);
+        rvb[i] = *(const u32x4*)(base + (2 * fp + 1) * fstride + 2 * C + c8 * 8);
+      }
+    }
+  };
+  auto stage = [&]() {
+    // q, k: rows as they are; v: transposed, a frame pair per dword
+#pragma unroll
+    for (int i = 0; i < IQK; ++i) {
+      const int it = tid + i * NT;
+      if (it < nqk) {
+        const int seg = it / (F * cpr), r = it - seg * (F * cpr);
+        const int f = r / cpr, c8 = r - f * cpr;
+        *(u32x4*)((seg ? sk : sq) + f * RS + c8 * 16) = rqk[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < IV; ++i) {
+      const int it = tid + i * NT;
+      if (it < nv) {
+        const int fp = it / cpr, c8 = it - fp * cpr;
+        const u32x4 va = rva[i], vb = rvb[i];
+        char* dst = svt + (c8 * 8) * VS + (((fp >> 2) ^ (c8 & 1)) << 4) + (fp & 3) * 4;   // rows c8*8 .. +7 share bit 3 = c8 & 1
+        // (a0 a1 | a2 a3 | ..) x (b0 b1 | ..) -> channel e: (a_e, b_e)
+        *(uint32_t*)(dst + 0 * VS) = __builtin_amdgcn_perm(vb.x, va.x, 0x05040100u);
+        *(uint32_t*)(dst + 1 * VS) = __builtin_amdgcn_perm(vb.x, va.x, 0x07060302u);
+        *(uint32_t*)(dst + 2 * VS) = __builtin_amdgcn_perm(vb.y, va.y, 0x05040100u);
+        *(uint32_t*)(dst + 3 * VS) = __builtin_amdgcn_perm(vb.y, va.y, 0x07060302u);
+        *(uint32_t*)(dst + 4 * VS) = __builtin_amdgcn_perm(vb.z, va.z, 0x05040100u);
+        *(uint32_t*)(dst + 5 * VS) = __builtin_amdgcn_perm(vb.z, va.z, 0x07060302u);
+        *(uint32_t*)(dst + 6 * VS) = __builtin_amdgcn_perm(vb.w, va.w, 0x05040100u);
+        *(uint32_t*)(dst + 7 * VS) = __builtin_amdgcn_perm(vb.w, va.w, 0x07060302u);
+      }
+    }
+  };
+  // every load of the block in flight before the first LDS write (written as load -> store pairs the block reached 3.1 TB/s at
+  // the 64x64 level whatever its arithmetic cost; a block walking several pixels with the next one's rows prefetched: no faster)
+  issue_loads(t);
+  stage();
+  __syncthreads();
+  const int col = lane & 15, lg = lane >> 4;     // accumulator column (query / key row of an operand) and lane group
+  const u32x4 zero4 = u32x4{0u, 0u, 0u, 0u};
+  for (int h = wave; h < hpg; h += NT / 64) {
+    const int hb = h * D * 2;
+    // ---- S^T = K Q^T ---------------------------------------------------------------------------------------------------
+    f32x4 sT = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < DQ; ++kk) {
+      const int ch = kk * 32 + lg * 8;            // first channel of this lane's 8
+      U4H8 ka, qb;
+      ka.u = zero4;
+      qb.u = zero4;
+      if (ch < D) {
+        ka.u = *(const u32x4*)(sk + col * RS + hb + ch * 2);
+        qb.u = *(const u32x4*)(sq + col * RS + hb + ch * 2);
+      }
+      sT = __builtin_amdgcn_mfma_f32_16x16x32_f16(ka.h, qb.h, sT, 0, 0, 0);
+    }
+    // ---- softmax over the 16 keys of query `col`: registers (keys 4 lg .. + 3) x lane groups -------------------------------
+    float mx = fmaxf(fmaxf(sT[0], sT[1]), fmaxf(sT[2], sT[3]));
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float pr[4];
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      pr[r] = __builtin_amdgcn_exp2f((sT[r] - mx) * scale_log2e);
+      sum += pr[r];
+    }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    // ---- P^T as the B operand: lane group 0 / 1 <- keys 0-7, 2 / 3 <- keys 8-15 (the duplicates meet zeros of V^T) ---------
+    H2U p01, p23;
+    p01.h = __builtin_amdgcn_cvt_pkrtz(pr[0], pr[1]);
+    p23.h = __builtin_amdgcn_cvt_pkrtz(pr[2], pr[3]);
+    const auto s0 = __builtin_amdgcn_permlane16_swap(p01.u, p01.u, false, false);
+    const auto s1 = __builtin_amdgcn_permlane16_swap(p23.u, p23.u, false, false);
+    U4H8 pb;
+    pb.u = u32x4{s0[0], s1[0], s0[1], s1[1]};     // keys 4 e .. + 3 of the even group, then of the odd group
+    // ---- O^T = V^T P^T ---------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      U4H8 va;
+      va.u = zero4;
+      const int vrow = h * D + dt * 16 + col;
+      if ((lg & 1) == 0) va.u = *(const u32x4*)(svt + vrow * VS + (((lg >> 1) ^ ((vrow >> 3) & 1)) << 4));
+      f32x4 o = __builtin_amdgcn_mfma_f32_16x16x32_f16(va.h, pb.h, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      const int c0 = dt * 16 + lg * 4;            // channels c0 .. c0 + 3 of the head, query `col`
+      if (c0 < D) {
+        union { u32x2 u; f16 e[4]; } ov;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ov.e[r] = (f16)(o[r] * inv);
+        *(u32x2*)(so + col * RS + hb + c0 * 2) = ov.u;
+      }
+    }
+  }
+  __syncthreads();
+  f16* ob = out + ((b * F) * (int64_t)T + t) * (int64_t)C + g * CG;
+  for (int it = tid; it < F * cpr; it += NT) {
+    const int f = it / cpr, c8 = it - f * cpr;
+    *(u32x4*)(ob + f * ((int64_t)T * C) + c8 * 8) = *(const u32x4*)(so + f * RS + c8 * 16);
+  }
+}
+
 }  // namespace
 
 extern "C" int anip_ref_attention_ex(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt,
@@ -589,12 +748,27 @@ extern "C" int anip_temporal_attention(const void* qkv, void* out, int B, int F,
   for (int c = heads; c >= 1; --c)
     if (heads % c == 0 && c * d <= 320 && c * F <= NT) { hpg = c; break; }
   ANIP_REQUIRE(hpg * F <= NT, "anip_temporal_attention: F=%d too large", F);
+  const float sl2 = scale * 1.4426950408889634f;
+  const int64_t blocks = (int64_t)B * T * (heads / hpg);
+  ANIP_REQUIRE(blocks < (1ll << 31), "anip_temporal_attention: grid too large");
+  static const int mfma_off = getenv("ANIP_TEMPORAL_MFMA") ? (atoi(getenv("ANIP_TEMPORAL_MFMA")) == 0) : 0;   // A/B against the v_dot2 kernel
+  if (F == 16 && !mfma_off && (d == 40 || d == 80 || d == 160)) {
+    const int CG = hpg * d;
+    const size_t lds16 = (size_t)2 * 16 * (CG * 2 + 16) + (size_t)(CG + 16) * 32;
+    const unsigned nblk = (unsigned)blocks;
+    AnipProfScope prof_(ANIP_K_TEMPORAL_ATTN, (void*)stream);
+    if (d == 40)
+      hipLaunchKernelGGL(temporal_attn16_kernel<40>, dim3(nblk), dim3(NT), lds16, (hipStream_t)stream, (const f16*)qkv, (f16*)out, T, heads, sl2, hpg);
+    else if (d == 80)
+      hipLaunchKernelGGL(temporal_attn16_kernel<80>, dim3(nblk), dim3(NT), lds16, (hipStream_t)stream, (const f16*)qkv, (f16*)out, T, heads, sl2, hpg);
+    else
+      hipLaunchKernelGGL(temporal_attn16_kernel<160>, dim3(nblk), dim3(NT), lds16, (hipStream_t)stream, (const f16*)qkv, (f16*)out, T, heads, sl2, hpg);
+    ANIP_LAUNCH_CHECK("anip_temporal_attention");
+    return 0;
+  }
   const int F2 = (F + 1) / 2;
   const size_t lds = (size_t)3 * (2 * F2) * hpg * d * sizeof(f16);   // q, k: 2*F2 rows; v: F2 rows of key pairs
   ANIP_REQUIRE(lds <= 65536, "anip_temporal_attention: LDS budget exceeded (F=%d d=%d)", F, d);
-  const int64_t blocks = (int64_t)B * T * (heads / hpg);
-  ANIP_REQUIRE(blocks < (1ll << 31), "anip_temporal_attention: grid too large");
-  const float sl2 = scale * 1.4426950408889634f;
   int SL = 1;                               // d-slices per item: power of two, <= chunks per head, all 256 threads used
   while (SL * 2 * hpg * F <= NT && SL * 2 <= (d >> 3)) SL *= 2;
   {

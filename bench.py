@@ -393,9 +393,9 @@ def main():
                 mf = v["unit"] == "TFLOP/s"
                 peak = MFMA_PEAK_TFLOPS if mf else HBM_PEAK_GBS
                 tr = traffic.get(name, {}).get("bytes_per_launch")
-                # what bounds the family: temporal attention moves its bytes at ~3 TB/s with the VALU 86 % busy (round-2 SQ
-                # pass) — it is VALU-bound, its byte rate is reported against the HBM peak for reference only
-                bound = "mfma" if mf else ("valu" if name == "temporal_attn_kernel" else "hbm")
+                # (temporal attention was VALU-bound through round 3 — v_dot2 scores and P V at ~3 TB/s; since round 4 its 16-frame
+                #  problems run on MFMA and the kernel moves its bytes at ~5 TB/s: HBM-bound like the norms)
+                bound = "mfma" if mf else "hbm"
                 return {"kernel": name, "bound": bound, "achieved": v["rate"], "peak": peak,
                         "unit": v["unit"], "frac": v["rate"] / peak, "traffic": tr,
                         "traffic_over_algorithmic_bytes": traffic.get(name, {}).get("traffic_over_algorithmic"),

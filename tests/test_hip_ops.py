@@ -530,7 +530,9 @@ def test_ref_attention_head_major_k():
 @pytest.mark.parametrize("B,Fr,T,heads,d", [(2, 16, 10, 8, 40), (1, 4, 7, 8, 8), (1, 24, 3, 8, 160), (2, 5, 6, 2, 16),
                                             (1, 32, 2, 8, 80),
                                             # more pixels than one block per CU; every head-group size (8 x 40, 4 x 80, 2 x 160)
-                                            (2, 16, 67, 8, 40), (1, 16, 33, 8, 80), (1, 16, 24, 8, 160), (1, 7, 19, 8, 40)])
+                                            (2, 16, 67, 8, 40), (1, 16, 33, 8, 80), (1, 16, 24, 8, 160), (1, 7, 19, 8, 40),
+                                            # the 16-frame MFMA kernel at a full level and with fewer channels than one 320-wide group
+                                            (2, 16, 1024, 8, 40), (1, 16, 50, 2, 40), (1, 16, 9, 16, 80)])
 def test_temporal_attention(B, Fr, T, heads, d):
     ops = _ops()
     Cc = heads * d
