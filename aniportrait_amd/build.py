@@ -32,7 +32,7 @@ def needs_build():
 
 
 def build(force=False, verbose=True, extra_flags=(), lib=None):
-    """extra_flags / lib: experiment builds (e.g. -DANIP_GEMM2_TIMING into lib/libaniportrait_hip_timing.so, loaded with
+    """extra_flags / lib: experiment builds (e.g. -DANIP_GELU_EXACT into lib/libaniportrait_hip_exact.so, loaded with
     ANIP_LIB=<path>); the product is always the flag-less default."""
     global LIB
     if lib is not None:

@@ -343,24 +343,14 @@ __global__ __launch_bounds__(NT, (D > 96 ? 1 : 2)) void ref_attn_kernel(const Re
   }
 }
 
-// query groups per wave: 1; ANIP_ATTN_QH=2 selects the two-group variant (d <= 40) for kernel experiments
+// one 32-query group per wave (two — the QH = 2 instantiation — measured no faster at twice the registers, round 2)
 template <int D>
 int launch_ref_attn(const RefAttnArgs& a, int Nf, hipStream_t stream) {
-  static const int force_qh = getenv("ANIP_ATTN_QH") ? atoi(getenv("ANIP_ATTN_QH")) : 0;
-  constexpr bool CAN2 = D <= 40;
-  const bool two = CAN2 && force_qh == 2;   // measured on MI355X (d = 40, T = 4096): no faster than one group per wave at twice the occupancy
-  dim3 grid((unsigned)((a.T + (two ? 255 : 127)) / (two ? 256 : 128)), (unsigned)a.heads, (unsigned)Nf);
+  dim3 grid((unsigned)((a.T + 127) / 128), (unsigned)a.heads, (unsigned)Nf);
   AnipProfScope prof_(ANIP_K_REF_ATTN, (void*)stream);
   const bool fits32 = (int64_t)KV * a.ldk < (1ll << 31) && (int64_t)KV * a.ldkr < (1ll << 31) &&
                       (int64_t)(D + 32) * a.ldvt < (1ll << 31) && (int64_t)(D + 32) * a.ldvtr < (1ll << 31);
   const bool fast = (a.T % KV) == 0 && a.vt_vec_ok && (a.ref_index == nullptr || a.vtref_vec_ok) && fits32;
-  if constexpr (CAN2) {
-    if (two) {
-      if (fast) hipLaunchKernelGGL((ref_attn_kernel<D, true, 2>), grid, dim3(NT), 0, stream, a);
-      else hipLaunchKernelGGL((ref_attn_kernel<D, false, 2>), grid, dim3(NT), 0, stream, a);
-      return 0;
-    }
-  }
   if (fast) hipLaunchKernelGGL((ref_attn_kernel<D, true, 1>), grid, dim3(NT), 0, stream, a);
   else hipLaunchKernelGGL((ref_attn_kernel<D, false, 1>), grid, dim3(NT), 0, stream, a);
   return 0;

@@ -3,7 +3,7 @@
 // Same mathematics and operand conventions as ref_attn_kernel (attention.hip): flash-style attention of 32-query groups
 // against 64-key tiles of [self tokens ++ reference-bank tokens], S^T = K Q^T with v_mfma_f32_32x32x16_f16, online softmax
 // with a lazily raised running maximum, O^T += V^T P^T.  What changed, each item decided by a measurement of this round
-// (tools/exp_valu_rates.*, tools/exp_attn_ablate.sh, profiles/r04/):
+// (tools/exp_valu_rates.*, profiles/r04/j_attn_dma_component_ablation.txt):
 //  * the kernel is CLOCK-limited on real data (the same launch runs 1.45 ms on random and 1.05 ms on all-zero operands), and
 //    leaving single components out of the tile loop prices them (random data, of 1405 us): all MFMAs 533 us, the K / V^T
 //    fragment reads LDS -> VGPR 517 us, the global -> LDS tile traffic 310 us, the 32 v_exp_f32 210 us, the tile maximum 63 us.
@@ -82,15 +82,6 @@ struct Geo {
 };
 
 #define ANIP_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
-
-// -DANIP_ATTN_ABLATE=<mask>: TIMING-ONLY experiment builds (wrong results) that leave one component of the tile loop out, to
-// price it on random data where the kernel is clock-limited (tools/exp_attn_ablate.sh): 1 no v_exp, 2 no P V MFMAs, 4 no
-// score MFMAs, 8 no K / V^T fragment reads (one read reused), 16 no LDS-DMA, 32 no tile maximum
-#ifndef ANIP_ATTN_ABLATE
-#define ANIP_ATTN_ABLATE 0
-#endif
-#define ABL(bit) ((ANIP_ATTN_ABLATE & (bit)) != 0)
-__device__ __forceinline__ float attn_exp2(float x) { return ABL(1) ? x : __builtin_amdgcn_exp2f(x); }
 
 }  // namespace
 
@@ -246,8 +237,8 @@ __global__ __launch_bounds__(NW * 64, (D <= 40 ? 4 : 2)) void ref_attn_dma_kerne
 #pragma unroll
     for (int kk = 0; kk < DQ; ++kk) {
       const bool last = kk == DQ - 1;
-      kf0[kk] = *(const f16x8*)(st + ((ABL(8) && kk > 0) ? koff : (last ? klast0 : koff + kk * 32)));
-      kf1[kk] = (ABL(8)) ? kf0[kk] : *(const f16x8*)(st + (last ? klast1 : koff + kk * 32 + KHALF));
+      kf0[kk] = *(const f16x8*)(st + (last ? klast0 : koff + kk * 32));
+      kf1[kk] = *(const f16x8*)(st + (last ? klast1 : koff + kk * 32 + KHALF));
     }
   };
   auto load_v = [&](const char* st) {
@@ -255,7 +246,7 @@ __global__ __launch_bounds__(NW * 64, (D <= 40 ? 4 : 2)) void ref_attn_dma_kerne
 #pragma unroll
       for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) vf[kc * DT + dt] = *(const f16x8*)(st + voff16[ABL(8) ? 0 : kc] + (ABL(8) ? 0 : dt) * 2048);
+        for (int dt = 0; dt < DT; ++dt) vf[kc * DT + dt] = *(const f16x8*)(st + voff16[kc] + dt * 2048);
     } else {
 #pragma unroll
       for (int gk = 0; gk < 4; ++gk)
@@ -271,8 +262,8 @@ __global__ __launch_bounds__(NW * 64, (D <= 40 ? 4 : 2)) void ref_attn_dma_kerne
   };
 
   __syncthreads();                        // constants visible (and no DMA in flight yet: the fence drains nothing)
-  if (!ABL(16)) issue_tile(0);
-  if (!ABL(16) && ntiles > 1) issue_tile(1);
+  issue_tile(0);
+  if (ntiles > 1) issue_tile(1);
 
   for (int t = 0; t < ntiles; ++t) {
     const char* st = smem + (t % NS) * G::STAGE;
@@ -280,7 +271,7 @@ __global__ __launch_bounds__(NW * 64, (D <= 40 ? 4 : 2)) void ref_attn_dma_kerne
     wait_tile(t + 1 < ntiles);
     __builtin_amdgcn_s_barrier();         // tile t complete for all waves; stage (t + 2) % NS (read at t - 1) is free
     asm volatile("" ::: "memory");
-    if (!ABL(16) && t + 2 < ntiles) issue_tile(t + 2);
+    if (t + 2 < ntiles) issue_tile(t + 2);
     load_k(st);
 
     // ---- S^T = K Q^T (- m): two 32-key x 32-query tiles per query group; every K fragment feeds all groups ------------------
@@ -294,15 +285,8 @@ __global__ __launch_bounds__(NW * 64, (D <= 40 ? 4 : 2)) void ref_attn_dma_kerne
       const f16x8 a0 = kf0[kk], a1 = kf1[kk];
 #pragma unroll
   for (int g = 0; g < QH; ++g) {
-        if (ABL(4)) {
-          if (kk == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s0[g][r] = (float)a0[r & 7] + (float)qf[g][0][r & 7]; s1[g][r] = (float)a1[r & 7] - (float)qf[g][1][r & 7]; }
-          }
-        } else {
-          s0[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, qf[g][kk], s0[g], 0, 0, 0);
-          s1[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, qf[g][kk], s1[g], 0, 0, 0);
-        }
+        s0[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, qf[g][kk], s0[g], 0, 0, 0);
+        s1[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, qf[g][kk], s1[g], 0, 0, 0);
       }
     }
     U4H8 pb[QH][4];
@@ -316,7 +300,6 @@ __global__ __launch_bounds__(NW * 64, (D <= 40 ? 4 : 2)) void ref_attn_dma_kerne
 #pragma unroll
       for (int r = 1; r < 15; r += 2) mx = fmaxf(fmaxf(mx, s1[g][r]), s1[g][r + 1]);
       mx = fmaxf(mx, s1[g][15]);
-      if (ABL(32)) mx = s0[g][0];
       mx = xor32_max(mx);
       // O^T *= alpha (alpha per query, held in the 32x32 layout: lane <-> query lane & 31)
       auto scale_o = [&](float alpha) {
@@ -377,10 +360,10 @@ __global__ __launch_bounds__(NW * 64, (D <= 40 ? 4 : 2)) void ref_attn_dma_kerne
       // ---- P^T fragments (B operand): slot (hi, j) of 16-key group gk <-> accumulator register 8 (gk & 1) + j of tile gk >> 1 ----
 #pragma unroll
       for (int j = 0; j < 8; j += 2) {
-        const float p00 = attn_exp2(s0[g][j]), p01 = attn_exp2(s0[g][j + 1]);
-        const float p10 = attn_exp2(s0[g][8 + j]), p11 = attn_exp2(s0[g][9 + j]);
-        const float p20 = attn_exp2(s1[g][j]), p21 = attn_exp2(s1[g][j + 1]);
-        const float p30 = attn_exp2(s1[g][8 + j]), p31 = attn_exp2(s1[g][9 + j]);
+        const float p00 = __builtin_amdgcn_exp2f(s0[g][j]), p01 = __builtin_amdgcn_exp2f(s0[g][j + 1]);
+        const float p10 = __builtin_amdgcn_exp2f(s0[g][8 + j]), p11 = __builtin_amdgcn_exp2f(s0[g][9 + j]);
+        const float p20 = __builtin_amdgcn_exp2f(s1[g][j]), p21 = __builtin_amdgcn_exp2f(s1[g][j + 1]);
+        const float p30 = __builtin_amdgcn_exp2f(s1[g][8 + j]), p31 = __builtin_amdgcn_exp2f(s1[g][9 + j]);
         if (!ONES) l_run[g] += ((p00 + p01) + (p10 + p11)) + ((p20 + p21) + (p30 + p31));
         pb[g][0].u[j >> 1] = pk_f16(p00, p01);
         pb[g][1].u[j >> 1] = pk_f16(p10, p11);
@@ -409,13 +392,8 @@ __global__ __launch_bounds__(NW * 64, (D <= 40 ? 4 : 2)) void ref_attn_dma_kerne
           const f16x8 av = vf[kc * DT + dt];
 #pragma unroll
   for (int g = 0; g < QH; ++g) {
-            if (ABL(2)) {
-              o16[g][dt][0][kc] += (float)av[dt] * (float)b0[g].h[dt];
-              o16[g][dt][1][kc] += (float)av[dt] * (float)b1[g].h[dt + 1];
-            } else {
-              o16[g][dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b0[g].h, o16[g][dt][0], 0, 0, 0);
-              o16[g][dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b1[g].h, o16[g][dt][1], 0, 0, 0);
-            }
+            o16[g][dt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b0[g].h, o16[g][dt][0], 0, 0, 0);
+            o16[g][dt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, b1[g].h, o16[g][dt][1], 0, 0, 0);
           }
         }
       }

@@ -43,11 +43,6 @@ namespace {
 
 constexpr uint32_t OOB = 0xFFFFFFF0u;
 
-// -DANIP_GEMM2_EXPERIMENTS compiles the main-loop ablation switches in (ANIP_GEMM2_DBG bit 2: no global->LDS traffic,
-// bit 4: no MFMAs).  They are runtime branches INSIDE the K loop — a uniform branch per 16-row fragment group, which
-// pins every A-fragment ds_read directly in front of its MFMAs with an lgkmcnt(0) between them — so production builds
-// leave them out; bits 1 (no epilogue) and 8 (round-1 epilogue) sit outside the loop and stay available.
-
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 // bank swizzle of the 16-B chunk index inside an LDS row (applied on the DMA SOURCE address and on the
@@ -73,10 +68,10 @@ __device__ __forceinline__ void row_swap(float& x, float& y) {
 //   256 x {256,320} x 64, 8 waves 2x4 (wave tile 128 x {64,80}), 2-stage, 1 block/CU — the global->LDS traffic per
 //     flop drops by 1/4..1/3 and every DMA row is a full 128-B line (BK = 32 rows are half lines), which is what
 //     bounds the smaller tiles (measured: DMA alone = 0.93 ms of the 1.18 ms 8192^3 GEMM).
-//   SCHED = 1 (wide tiles only): the quarter-phased main loop (round 3), see "quarter-phased schedule" below.
-template <int BM2, int BN, int NW, int WNW, int BKT, int NST, bool CONV, bool TRANS, int SCHED = 0, bool LNF = false>
+//   wide tiles (NST = 2, BK = 64, 8 waves): the quarter-phased main loop (round 3), see "quarter-phased schedule" below.
+template <int BM2, int BN, int NW, int WNW, int BKT, int NST, bool CONV, bool TRANS, bool LNF = false>
 __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void gemm2_kernel(const anip_gemm_params p,
-                                                                                           const int dbg, const int splitk) {
+                                                                                           const int skip_epilogue, const int splitk) {
   constexpr int NT2 = NW * 64;
   constexpr int RB = BKT * 2;                  // LDS row bytes
   constexpr int CPR = RB / 16;                 // 16-B chunks per row
@@ -116,7 +111,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
       constexpr int GM = 8;
       // (only when the weight matrix does not fit an XCD's L2 next to the streaming A panels: with a resident W — the
       // 64x64 ff-in, 1.6 MB — row-major order reads every operand exactly once and measured 4 % faster)
-      if (nbn >= 8 && (int64_t)p.N * p.K * 2 > (2 << 20) && !(dbg & 32)) {
+      if (nbn >= 8 && (int64_t)p.N * p.K * 2 > (2 << 20)) {
         const int per = GM * nbn, grp_ = swz / per, first = grp_ * GM, rem = swz - grp_ * per;
         const int gsz = min(nbm - first, GM);
         bm = first + rem % gsz;
@@ -131,19 +126,6 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
   };
   int vb = blockIdx.x, m0, n0;
   tile_of(vb, m0, n0);
-
-  // experiment (ANIP_GEMM2_DBG bits 8-15 = k, bits 16-17 = who): a subset of the blocks sleeps k x 8128 cycles before
-  // it starts, to put blocks out of phase (some in their load-heavy main loop while others store).  who = 0: the second
-  // dispatch round (the co-resident partner on a CU), 1: odd XCDs (block id parity), 2: odd compute units (HW_ID.CU_ID)
-  if (((dbg >> 8) & 0xFF) != 0) {
-    const int who = (dbg >> 16) & 3;
-    bool late;
-    if (who == 0) late = (blockIdx.x >> 8) & 1;
-    else if (who == 1) late = blockIdx.x & 1;
-    else late = __builtin_amdgcn_s_getreg((4) | (8 << 6) | (3 << 11)) & 1;
-    if (late)
-      for (int i = 0; i < ((dbg >> 8) & 0xFF); ++i) __builtin_amdgcn_s_sleep(127);
-  }
 
   const f16* Ap = (const f16*)p.A;
   const f16* Wp = (const f16*)p.W;
@@ -177,11 +159,11 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
   // 16-B chunk (within the K-tile's row) this lane fetches: the swizzle depends on the row inside the instruction's row
   // group only (the groups start at multiples of 8 / 16 rows), so it is the same for every A instruction of the lane
   const int a_g = ls ^ swz_of<BKT>(lr);
-  // RPI-row block of the A tile that this wave's i-th DMA instruction fills.  SCHED 0: blocks wave*NA_I + i.
-  // SCHED 1 (BM2 = 256, 8 waves 2 x 4, NA_I = 4): instructions 0, 1 fill "A-lo" blocks — the first 64 rows of each
+  // RPI-row block of the A tile that this wave's i-th DMA instruction fills.  Narrow tiles: blocks wave*NA_I + i.
+  // Wide tiles (BM2 = 256, 8 waves 2 x 4, NA_I = 4): instructions 0, 1 fill "A-lo" blocks — the first 64 rows of each
   // 128-row wave-row band — and 2, 3 the "A-hi" blocks, so that the two halves can be staged (and waited for) separately.
   auto a_blk = [&](int i) -> int {
-    if (SCHED == 0) return wave * NA_I + i;
+    if (!(NST == 2 && BKT == 64 && NW == 8)) return wave * NA_I + i;
     const int r = 2 * wave + (i & 1);            // 0..15 within the half
     return (r >> 3) * 16 + (i >> 1) * 8 + (r & 7);
   };
@@ -280,9 +262,6 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(sb + (wave + NW * i) * 1024), 16, vo, (uint32_t)k0 * 2u, 0, 0);
   };
   auto issue = [&](int kt, int stage) {
-#ifdef ANIP_GEMM2_EXPERIMENTS
-    if (dbg & 2) return;   // experiment: no global->LDS traffic
-#endif
 #pragma unroll
     for (int i = 0; i < NA_I; ++i) issue_a1(kt, stage, i);
 #pragma unroll
@@ -318,10 +297,10 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
     kt_begin = (int)blockIdx.y * per;
     nk = max(0, min(nk - kt_begin, per));
   }
-  constexpr bool PHASED = (NST == 2 && KH == 2 && NW == 8);
+  constexpr bool PHASED = (NST == 2 && KH == 2 && NW == 8);   // the wide tiles: quarter-phased main loop, persistent walk
   f32x4 acc[FM][NB];
 
-  // ======== quarter-phased schedule (PHASED && SCHED >= 1): state, DMA operand preparation, prologue ========
+  // ======== quarter-phased schedule (PHASED): state, DMA operand preparation, prologue ========
   // Quarter-phased schedule (round 3).  Round 2's role-alternating loop below issues the WHOLE next K-tile (8-9 LDS-DMA
   // instructions per wave, 36 KiB per wave group through the CU's one 64 B/clk address path) inside ONE of its four
   // load segments per K-tile and drains it (vmcnt(0)) once per K-tile: that segment is ~3x longer than the 32-MFMA
@@ -345,7 +324,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
   //        K-tile later, and every LOAD ends with lgkmcnt(0) before its barrier.
   // (First version of this loop: both B fragment sets live, A-hi needed only at j=2.  The 256 x 320 convolution kernel
   // then sits at 253-256 VGPRs and any extra state spills INTO the loop: 3x slower, profiles/r03/h_*.)
-  if constexpr (PHASED && SCHED >= 1) {
+  if constexpr (PHASED) {
     static_assert(FM == 8 && NA_I == 4 && NB_TOT % NW == 0, "quarter-phased schedule: 256-row tile, 2 x 4 waves");
   }
   // DMA operands of the NEXT K-tile are PREPARED inside a compute segment (scalar / vector address arithmetic hides
@@ -451,27 +430,14 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
   };
   f16x8 bf[NB], af[4];
   const int a_lo = a_row_off, a_hi = a_row_off + 64 * RB;
-  // SCHED 3 (experiment builds only, -DANIP_GEMM2_TIMING; measured 2-5 % slower than SCHED 1 on every wide shape — without
-  // the mid-step rendezvous the two waves of a SIMD drift into computing / loading at the same time): ONE barrier per
-  // sub-step instead of two.  Both wave groups run the same stream L0 C0 L1 C1 ...; group 0
-  // passes a barrier after every COMPUTE, group 1 after every LOAD, so between two barriers one wave of a SIMD runs
-  // [LOAD(s), COMPUTE(s)] while its partner runs [COMPUTE(s-1), LOAD(s)]: first half load || compute, second half
-  // compute || load, with no rendezvous in the middle.  An interval then costs L + C of one wave instead of
-  // 2 x max(L, C) (measured: LOAD 315-580 vs COMPUTE 320-400 cycles, profiles/r03/i_*), and four barrier round trips
-  // per K-tile disappear.  Hazards as above with barrier #s closing sub-step s for both groups: every wait sits in a
-  // LOAD that precedes the barrier the readers pass before they read (RAW), and every re-staged region was last read
-  // at least one barrier earlier (WAR: the tightest pair is A-lo, read last at j=3 of tile t-1, re-staged at j=2 of t).
-  constexpr bool HALF_BAR = (SCHED == 3);
+  // (One barrier per sub-step instead of two — without the mid-step rendezvous — was measured 2-5 % slower on every wide shape,
+  //  profiles/r03/t_kbench_*: the two waves of a SIMD drift into computing / loading at the same time.)
 #define ANIP_G2_BAR_RAW()            \
   __builtin_amdgcn_sched_barrier(0); \
   __builtin_amdgcn_s_barrier();      \
   __builtin_amdgcn_sched_barrier(0)
-#define ANIP_G2_BAR_L()                             \
-  if (!HALF_BAR || grp == 1) { ANIP_G2_BAR_RAW(); } \
-  else { __builtin_amdgcn_sched_barrier(0); }
-#define ANIP_G2_BAR_C()                             \
-  if (!HALF_BAR || grp == 0) { ANIP_G2_BAR_RAW(); } \
-  else { __builtin_amdgcn_sched_barrier(0); }
+#define ANIP_G2_BAR_L() ANIP_G2_BAR_RAW()
+#define ANIP_G2_BAR_C() ANIP_G2_BAR_RAW()
 #define ANIP_G2_MMA(I0)                                                                                           \
   __builtin_amdgcn_s_setprio(1);                                                                                  \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < NB; ++j)                    \
@@ -484,25 +450,8 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
 #define ANIP_G2_DMA_A(I)    \
   if (CONV) fire_a(nst, I); \
   else issue_a1(kt_begin + t + 1, nst, I)
-  // SCHED == 2 (-DANIP_GEMM2_TIMING builds only): the same loop with s_memtime stamps around every segment and barrier;
-  // waves 0 and 4 of the middle block write, per sub-step j, the summed cycles of [LOAD work, wait at the barrier
-  // closing LOAD, COMPUTE work, wait at the barrier closing COMPUTE] to p.workspace (tools/exp_gemm_timing.py)
-  constexpr bool TIMED = (SCHED == 2);
-  uint32_t tacc[20];      // [4j + {LOAD, barrier, COMPUTE, barrier}], [16 + j]: LOAD up to lgkmcnt(0), the rest of LOAD = DMA wait
-  uint64_t tprev = 0;
-  if (TIMED) {
-#pragma unroll
-    for (int q = 0; q < 20; ++q) tacc[q] = 0;
-    tprev = __builtin_readcyclecounter();
-  }
-#define ANIP_G2_STAMP(Q)                                \
-  if (TIMED) {                                          \
-    const uint64_t now_ = __builtin_readcyclecounter(); \
-    tacc[Q] += (uint32_t)(now_ - tprev);                \
-    tprev = now_;                                       \
-  }
   const int grp = wave >> 2;
-  if constexpr (PHASED && SCHED >= 1) {
+  if constexpr (PHASED) {
     if (nk > 0) issue(kt_begin, 0);
     if (CONV && nk > 1) prepare(kt_begin + 1);
   }
@@ -515,7 +464,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
   // kernel-argument loads and the exposed HBM round trip of a fresh workgroup (5-14 % of a K <= 1280 tile).
   for (;;) {
     const int vbn = vb + (int)gridDim.x;
-    const bool has_next = (PHASED && SCHED >= 1) && vbn < nblk;   // block-uniform
+    const bool has_next = (PHASED) && vbn < nblk;   // block-uniform
     int m0n = 0, n0n = 0;
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -525,7 +474,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
     // start the accumulators from the per-column additive terms (bias and, when the block's rows share one row group,
     // the row-group bias): NB small L2-resident loads that travel with the prologue DMA, no registers, and nothing
     // left to fetch for them in the epilogue, where loads queue behind the tile's stores (see there).
-    const bool acc_has_bias = !TRANS && !(dbg & 8) && splitk <= 1 && p.alpha == 1.0f && !LNF && m0 + BM2 <= p.M && n0 + BN <= p.N &&
+    const bool acc_has_bias = !TRANS && splitk <= 1 && p.alpha == 1.0f && !LNF && m0 + BM2 <= p.M && n0 + BN <= p.N &&
                               (p.bias != nullptr || p.rowbias != nullptr) &&
                               (p.rowbias == nullptr || (((p.ld_rowbias & 3) == 0) && ((((uintptr_t)p.rowbias) & 15) == 0)));
     const bool rb_uni = acc_has_bias && p.rowbias != nullptr &&
@@ -543,12 +492,12 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
       }
     }
 
-    if constexpr (PHASED && SCHED >= 1) {
+    if constexpr (PHASED) {
       // K-tile 0 (issued in front of the tile loop / in front of the previous tile's epilogue) has landed for every wave;
       // on a later tile of a walk the counter also covers the previous tile's stores (in order: they were issued later)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (SCHED != 3 && grp == 1) __builtin_amdgcn_s_barrier();
+      if (grp == 1) __builtin_amdgcn_s_barrier();
       for (int t = 0; t < nk; ++t) {
         const char* sa = smem + (t & 1) * STAGE;
         const char* sb = sa + A_BYTES;
@@ -562,18 +511,13 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
         if (more) {
           ANIP_G2_DMA_B(0);
           ANIP_G2_DMA_B(1);
-          if (TIMED) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ANIP_G2_STAMP(16); }
           asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");   // leaves the 2 B blocks just issued: A-hi(t) landed
         } else {
           asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
-        ANIP_G2_STAMP(0);
         ANIP_G2_BAR_L();
-        ANIP_G2_STAMP(1);
         ANIP_G2_MMA(0);
-        ANIP_G2_STAMP(2);
         ANIP_G2_BAR_C();
-        ANIP_G2_STAMP(3);
         // ---- j = 1: A-hi x B(k-half 0); stage the remaining B blocks
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i] = *(const f16x8*)(sa + a_hi + i * 16 * RB + koff[0]);
@@ -582,13 +526,9 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
           for (int i = 2; i < NB_I; ++i) { ANIP_G2_DMA_B(i); }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        ANIP_G2_STAMP(4);
         ANIP_G2_BAR_L();
-        ANIP_G2_STAMP(5);
         ANIP_G2_MMA(4);
-        ANIP_G2_STAMP(6);
         ANIP_G2_BAR_C();
-        ANIP_G2_STAMP(7);
         // ---- j = 2: A-hi x B(k-half 1) (the B fragments are replaced: one set of B registers); stage A-lo of tile t+1
 #pragma unroll
         for (int j = 0; j < NB; ++j) bf[j] = *(const f16x8*)(sb + (tile_c(j) + fr) * RB + koff[1]);
@@ -599,37 +539,28 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
           ANIP_G2_DMA_A(1);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        ANIP_G2_STAMP(8);
         ANIP_G2_BAR_L();
-        ANIP_G2_STAMP(9);
         ANIP_G2_MMA(4);
-        ANIP_G2_STAMP(10);
         ANIP_G2_BAR_C();
-        ANIP_G2_STAMP(11);
         // ---- j = 3: A-lo x B(k-half 1); stage A-hi of tile t+1; everything of tile t+1 but that must have landed
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i] = *(const f16x8*)(sa + a_lo + i * 16 * RB + koff[1]);
         if (more) {
           ANIP_G2_DMA_A(2);
           ANIP_G2_DMA_A(3);
-          if (TIMED) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ANIP_G2_STAMP(19); }
           asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
         } else {
           asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         }
-        ANIP_G2_STAMP(12);
         ANIP_G2_BAR_L();
-        ANIP_G2_STAMP(13);
         ANIP_G2_MMA(0);
         // conv: the scalar operands of tile t+2 (its first part is fired in the next load segment) behind these MFMAs.
         // (The plain GEMM issues with its per-instruction arithmetic in place: hoisting it measured 4-6 % SLOWER —
         // the main loop waits for DMA data, not for instruction issue; profiles/r03/e_kbench_prepared_operands.jsonl.)
         if (CONV && t + 2 < nk) prepare(kt_begin + t + 2);
-        ANIP_G2_STAMP(14);
         ANIP_G2_BAR_C();
-        ANIP_G2_STAMP(15);
       }
-      if (SCHED != 3 && grp == 0) __builtin_amdgcn_s_barrier();   // closing rendezvous: group 1 has finished its last LOAD
+      if (grp == 0) __builtin_amdgcn_s_barrier();   // closing rendezvous: group 1 has finished its last LOAD
       if (has_next) {
         tile_of(vbn, m0n, n0n);
         setup_lanes(m0n, n0n);
@@ -639,54 +570,6 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
           prepare(kt_begin + 1);
         }
       }
-    } else if (PHASED) {
-      // Role-alternating schedule for the one-block-per-CU wide tiles.  A K-tile is two 32-deep steps; every step is a
-      // LOAD segment (all ds_reads of the step's fragments, plus the DMA issue of the next K-tile on the first step)
-      // and a COMPUTE segment (FM x NB MFMAs on registers only), each closed by an s_barrier.  Waves 4-7 run one
-      // barrier behind waves 0-3 (they execute one extra barrier up front, waves 0-3 one at the end), so on every SIMD
-      // — waves w and w+4 share one — a wave's COMPUTE segment always coincides with its partner's LOAD segment: the
-      // matrix pipe never waits for LDS or for the barrier.
-      //   barrier numbering: group 0 passes #2s after LOAD(s) and #2s+1 after COMPUTE(s); group 1 passes #2s+1 after
-      //   LOAD(s) and #2s+2 after COMPUTE(s).  K-tile t+1 is issued in LOAD(2t) (its stage was last read in LOAD(2t-1),
-      //   complete before #4t-1) and every wave drains its DMA before #4t+3, after which the first reads of tile t+1 follow.
-      const int grp = wave >> 2;
-      if (nk > 0) issue(kt_begin, 0);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (grp == 1) __builtin_amdgcn_s_barrier();
-      for (int s2 = 0; s2 < 2 * nk; ++s2) {
-        const int t = s2 >> 1, kh = s2 & 1;
-        if (kh == 0 && t + 1 < nk) issue(kt_begin + t + 1, (t + 1) & 1);
-        const char* sa = smem + (t & 1) * STAGE;
-        const char* sb = sa + A_BYTES;
-        const int ko = kh ? koff[KH - 1] : koff[0];
-        f16x8 af[FM], bf[NB];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) bf[j] = *(const f16x8*)(sb + (tile_c(j) + fr) * RB + ko);
-#pragma unroll
-        for (int i = 0; i < FM; ++i) af[i] = *(const f16x8*)(sa + a_row_off + i * 16 * RB + ko);
-        if (grp == 1 && kh == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#ifdef ANIP_GEMM2_EXPERIMENTS
-        if (!(dbg & 4))
-#endif
-#pragma unroll
-          for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < NB; ++j)
-              acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0)
-                                : __builtin_amdgcn_mfma_f32_16x16x32_f16(bf[j], af[i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        if (grp == 0 && kh == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (grp == 0) __builtin_amdgcn_s_barrier();
     } else {
 #pragma unroll
       for (int t = 0; t < NST - 1; ++t)
@@ -711,9 +594,6 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
 #pragma unroll
           for (int i = 0; i < FM; ++i) {
             const f16x8 af = *(const f16x8*)(sa + a_row_off + i * 16 * RB + koff[kh]);
-#ifdef ANIP_GEMM2_EXPERIMENTS
-            if (!(dbg & 4))      // experiment: no MFMAs
-#endif
 #pragma unroll
               for (int j = 0; j < NB; ++j)
                 acc[i][j] = TRANS ? __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[j], acc[i][j], 0, 0, 0)
@@ -726,7 +606,11 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
     // ---- epilogue: straight from the accumulators ------------------------------------------------------
     //   !TRANS: acc[i][j][r] = C[m0 + wm*WTM + i*16 + fr][n0 + wn*WTN + j*16 + fq*4 + r]
     //    TRANS: acc[i][j][r] = C[m0 + wm*WTM + i*16 + fq*4 + r][n0 + wn*WTN + j*16 + fr]
-    if (dbg & 1) {           // experiment: no epilogue (keep the accumulators live)
+    // An exit that uses the accumulators as they leave the main loop; `skip_epilogue` is 0 in every launch.  It is here for the
+    // register allocator: without a use of `acc` at this point the 256 x 256 instantiations spill 60 dwords more and the
+    // convolution one reloads values INSIDE its main loop (16 scratch loads per K-tile: the VAE's 256-channel 256x256 convolution
+    // 1.40 -> 2.14 ms) — found when round 3's "no epilogue" experiment switch, which sat here, was pruned.
+    if (skip_epilogue) {
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -996,7 +880,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
       // path) takes the tight epilogue below; ragged tiles take the general per-element-guarded one.
       const bool has_rb = p.rowbias != nullptr, has_res = p.residual != nullptr;
       // (32-bit per-lane byte offsets: the output / residual extents must stay below 4 GiB)
-      const bool tight = !(dbg & 8) && m0 + BM2 <= p.M && n0 + BN <= p.N &&
+      const bool tight = m0 + BM2 <= p.M && n0 + BN <= p.N &&
                          (p.out_f32 ? (p.ldo & 3) == 0 : ((p.head_dim > 0 ? p.head_dim : p.ldo) & 7) == 0) &&
                          (!has_res || (p.ldr & 7) == 0) &&
                          (bias_in_acc || (p.bias == nullptr && !has_rb)) &&
@@ -1051,11 +935,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
         // column pair are in flight together before the first of their stores; bias and block-uniform row-group bias
         // are already inside the accumulators.  (RBAT: what the 128-VGPR budget of the 4-waves-per-SIMD tiles allows.)
         constexpr int RBAT = (NW == 8 && WNW == 2 && NB == 5) ? 2 : FM;   // 256 x 160, 4 waves per SIMD: 128 VGPRs
-#ifdef ANIP_GEMM2_PAIR_EPILOGUE
-        constexpr bool QUAD = false;           // experiment builds: round 2's 64-B row segments
-#else
         constexpr bool QUAD = (NB == 4 || NB == 5);
-#endif
         // addressing: wave-uniform 64-bit bases (+ the uniform 16-row step) in SGPRs, one 32-bit per-lane BYTE offset —
         // 64-bit per-lane pointers for every (row block, column pair) do not fit the 128-VGPR budget next to the
         // accumulators
@@ -1084,40 +964,18 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
           const uint32_t rn = (uint32_t)mq * ldr_b + (uint32_t)n * 2u;
           const uint32_t on = (uint32_t)mq * ldo_b + (hm ? ((uint32_t)(n / p.head_dim) * (uint32_t)p.M * (uint32_t)p.head_dim +
                                                            (uint32_t)(n % p.head_dim)) : (uint32_t)n) * esz;
-          // Experiment (ANIP_GEMM2_DBG bit 6; the one-tile-per-workgroup forms): the wave's residual sub-tile — WTM rows x
-          // 128 B — is fetched by LDS-DMA into the wave's own slice of the operand ring the main loop has vacated, ALL of it
-          // in flight at once, instead of one 16-row block of register loads per HBM round trip (the 128-VGPR budget of the
-          // 256 x 160 tiles allows no more): cache-cold, the N = K = 320 residual layers spend 101 us against 57 us warm
-          // (profiles/r03/zj_*), most of the difference in those dependent round trips.
-          constexpr bool RES_LDS_OK = !PHASED && (NST * (BM2 + BN) * BKT * 2) / NW >= WTM * 128;
-          const bool res_lds = RES_LDS_OK && has_res && (dbg & 64) != 0;
-          const char* rl = smem + wave * (WTM * 128);
-          if (RES_LDS_OK && res_lds) {
-            __builtin_amdgcn_s_barrier();                       // every wave has finished reading the operand ring
-            auto rR = __builtin_amdgcn_make_buffer_rsrc((void*)p.residual, 0, (uint32_t)((int64_t)p.M * p.ldr * 2), 0x00020000);
-            const uint32_t v0 = (uint32_t)(m0 + wm * WTM + (lane >> 3)) * ldr_b + (uint32_t)(n0 + tile_c(0) + (lane & 7) * 8) * 2u;
-#pragma unroll
-            for (int q = 0; q < WTM / 8; ++q)                   // 8 rows x 128 B per instruction, lane-linear in LDS
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(rR, LDS_PTR(rl + q * 1024), 16, v0 + (uint32_t)(q * 8) * ldr_b, 0, 0, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          }
-          const int rl_off = r8 * 128 + ((fr >> 3) * 4 + tsel * 2 + (fq >> 1)) * 16;   // this lane's 16 B of row r8 in the slice
+          // (The residual sub-tile fetched by LDS-DMA into the vacated operand ring, all of it in flight at once, measured + 5 %
+          //  cache-cold on the N = K = 320 residual layers and nothing in the pipeline, profiles/r03/zk_*: not kept.)
 #pragma unroll
           for (int ib = 0; ib < FM; ib += RBQ) {
             U4H8 resA[RBQ], resB[RBQ];
-            if (RES_LDS_OK && res_lds) {
-#pragma unroll
-              for (int i = 0; i < RBQ; ++i) {
-                resA[i].u = *(const u32x4*)(rl + ((ib + i) * 16) * 128 + rl_off);
-                resB[i].u = *(const u32x4*)(rl + ((ib + i) * 16 + 8) * 128 + rl_off);
-              }
-            } else if (has_res) {
+            if (has_res) {
 #pragma unroll
               for (int i = 0; i < RBQ; ++i) {
                 resA[i].u = *(const u32x4*)(resb + (size_t)((ib + i) * 16) * ldr_b + rn);
                 resB[i].u = *(const u32x4*)(resb + (size_t)((ib + i) * 16 + 8) * ldr_b + rn);
               }
-            } else if (PHASED && SCHED >= 1) {   // (defined either way: an undefined value becomes loop-carried state of the tile loop)
+            } else if (PHASED) {   // (defined either way: an undefined value becomes loop-carried state of the tile loop)
 #pragma unroll
               for (int i = 0; i < RBQ; ++i) {
                 resA[i].u = u32x4{0u, 0u, 0u, 0u};
@@ -1187,7 +1045,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
               if (has_res) {
 #pragma unroll
                 for (int i = 0; i < RBAT; ++i) res[i].u = *(const u32x4*)(resb + (size_t)((ib + i) * 16) * ldr_b + rn);
-              } else if (PHASED && SCHED >= 1) {   // (defined either way: an undefined value becomes loop-carried state of the tile loop)
+              } else if (PHASED) {   // (defined either way: an undefined value becomes loop-carried state of the tile loop)
 #pragma unroll
                 for (int i = 0; i < RBAT; ++i) res[i].u = u32x4{0u, 0u, 0u, 0u};
               }
@@ -1238,7 +1096,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
             if (has_res) {
 #pragma unroll
               for (int i = 0; i < RBAT; ++i) res[i].u = *(const u32x2*)(resb + (size_t)((ib + i) * 16) * ldr_b + rn);
-            } else if (PHASED && SCHED >= 1) {
+            } else if (PHASED) {
 #pragma unroll
               for (int i = 0; i < RBAT; ++i) res[i].u = u32x2{0u, 0u};
             }
@@ -1273,15 +1131,6 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
     m0 = m0n;
     n0 = n0n;
   }
-  if constexpr (PHASED && SCHED >= 1) {
-    if (TIMED && p.workspace != nullptr && blockIdx.x == gridDim.x / 2 && (wave & 3) == 0 && lane == 0) {
-      uint32_t* o = (uint32_t*)p.workspace + grp * 32;
-#pragma unroll
-      for (int q = 0; q < 20; ++q) o[q] = tacc[q];
-      o[20] = (uint32_t)nk;
-    }
-  }
-#undef ANIP_G2_STAMP
 #undef ANIP_G2_DMA_A
 #undef ANIP_G2_DMA_B
 #undef ANIP_G2_BAR_RAW
@@ -1290,12 +1139,6 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
 #undef ANIP_G2_MMA
 }
 
-// ANIP_GEMM2_PERSIST: 1 (default) = persistent walk for the quarter-phased wide tiles (see launch_gemm2), 0 = one workgroup
-// per tile
-inline int gemm2_persistent() {
-  static const int v = getenv("ANIP_GEMM2_PERSIST") ? atoi(getenv("ANIP_GEMM2_PERSIST")) : 1;
-  return v;
-}
 inline int gemm2_device() {             // ordinal of the current device, clamped into the per-device caches below
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
@@ -1313,7 +1156,7 @@ inline int gemm2_cu_count() {           // per device: partitions of one node ma
 
 static thread_local bool g_gemm2_dry_run = false;   // anip_gemm2_would_take: walk the dispatch, launch nothing
 
-template <int BM2, int BN, int NW, int WNW, int BKT, int NST, bool CONV, bool TRANS, int SCHED = 0, bool LNF = false>
+template <int BM2, int BN, int NW, int WNW, int BKT, int NST, bool CONV, bool TRANS, bool LNF = false>
 int launch_gemm2(const anip_gemm_params& p, hipStream_t stream, int splitk = 1) {
   constexpr int NT2 = NW * 64;
   if (g_gemm2_dry_run) return 1;
@@ -1321,61 +1164,32 @@ int launch_gemm2(const anip_gemm_params& p, hipStream_t stream, int splitk = 1) 
   static bool attr_done_dev[16] = {};   // the attribute is per device
   bool& attr_done = attr_done_dev[gemm2_device()];
   if (!attr_done) {
-    auto kfn = gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS, SCHED, LNF>;
+    auto kfn = gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS, LNF>;
     if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
       anip_set_error("anip_gemm: cannot raise the dynamic LDS limit to %d bytes", LDS);
       return -2;
     }
     attr_done = true;
   }
-  static const int dbg = getenv("ANIP_GEMM2_DBG") ? atoi(getenv("ANIP_GEMM2_DBG")) : 0;  // kernel experiments only
   const int nbm = (p.M + BM2 - 1) / BM2, nbn = (p.N + BN - 1) / BN;
   unsigned grid = (unsigned)(nbm * nbn);
   // Persistent form of the quarter-phased wide tiles (one workgroup per CU: 147 KB of LDS): a launch with more tiles than
   // CUs starts one workgroup per CU, and each walks tiles blockIdx.x, + gridDim.x, ... with the first K-tile of the next
   // tile staged under the epilogue of the running one (see the tile loop in the kernel).
-  if (SCHED == 1 && NST == 2 && gemm2_persistent() && p.batch <= 1 && splitk <= 1 && (p.K + BKT - 1) / BKT >= 2) {
+  if (NST == 2 && BKT == 64 && NW == 8 && p.batch <= 1 && splitk <= 1 && (p.K + BKT - 1) / BKT >= 2) {
     const unsigned ncu = (unsigned)gemm2_cu_count();
     if (ncu >= 8 && (ncu & 7) == 0 && grid > ncu) grid = ncu;
   }
-  hipLaunchKernelGGL((gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS, SCHED, LNF>), dim3(grid, (unsigned)p.batch, 1),
-                     dim3(NT2), LDS, stream, p, dbg, splitk);
+  hipLaunchKernelGGL((gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS, LNF>), dim3(grid, (unsigned)p.batch, 1),
+                     dim3(NT2), LDS, stream, p, 0, splitk);
   return 1;
-}
-
-// main-loop schedule of the wide (256-row, BK = 64, one block per CU) tiles: 1 = quarter-phased (round 3, default),
-// 0 = round 2's role-alternating loop (ANIP_GEMM2_SCHED=0; kept for A/B measurements)
-static int gemm2_sched() {
-  static const int v = getenv("ANIP_GEMM2_SCHED") ? atoi(getenv("ANIP_GEMM2_SCHED")) : 1;
-  return v;
 }
 
 template <int BM2, int BN, int NW, int WNW, int BKT, int NST>
 int dispatch_gemm2(const anip_gemm_params& p, hipStream_t stream, int splitk = 1) {
-  if constexpr (NST == 2 && BKT == 64 && NW == 8) {
-#ifdef ANIP_GEMM2_TIMING
-    if (gemm2_sched() == 3) {     // one barrier per sub-step: measured 2-5 % SLOWER than SCHED 1 (profiles/r03/t_kbench_*)
-      if (p.conv) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, true, false, 3>(p, stream, splitk);
-      if (p.trans_out) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, true, 3>(p, stream, splitk);
-      return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, false, 3>(p, stream, splitk);
-    }
-    if (gemm2_sched() == 2) {
-      if (p.conv) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, true, false, 2>(p, stream, splitk);
-      return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, false, 2>(p, stream, splitk);
-    }
-#endif
-    if (gemm2_sched() == 1) {
-      if (p.ln_stats != nullptr && !p.conv)      // LayerNorm fold: its own instantiations
-        return p.trans_out ? launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, true, 1, true>(p, stream, splitk)
-                           : launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, false, 1, true>(p, stream, splitk);
-      if (p.conv) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, true, false, 1>(p, stream, splitk);
-      if (p.trans_out) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, true, 1>(p, stream, splitk);
-      return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, false, 1>(p, stream, splitk);
-    }
-  }
-  if (p.ln_stats != nullptr && !p.conv)
-    return p.trans_out ? launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, true, 0, true>(p, stream, splitk)
-                       : launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, false, 0, true>(p, stream, splitk);
+  if (p.ln_stats != nullptr && !p.conv)      // LayerNorm fold: its own instantiations
+    return p.trans_out ? launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, true, true>(p, stream, splitk)
+                       : launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, false, true>(p, stream, splitk);
   if (p.conv) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, true, false>(p, stream, splitk);
   if (p.trans_out) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, true>(p, stream, splitk);
   return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, false>(p, stream, splitk);
@@ -1440,8 +1254,8 @@ static int gemm2_split(const anip_gemm_params& p, int* cfg) {
   if (p.conv ? (p.Cin % 32 != 0) : (p.A2 != nullptr && (p.K1 % 32) != 0)) return 1;
   if ((((uintptr_t)p.bias | (uintptr_t)p.rowbias) & 15) != 0) return 1;
   // experiment knobs: smallest M that takes the wide-tile split (default 2048: the 8x8 level), most slices (default 8)
-  static const int wsplit_min_m = getenv("ANIP_GEMM2_WSPLIT_MINM") ? atoi(getenv("ANIP_GEMM2_WSPLIT_MINM")) : 2048;
-  static const int wsplit_max_s = getenv("ANIP_GEMM2_WSPLIT_MAXS") ? atoi(getenv("ANIP_GEMM2_WSPLIT_MAXS")) : 8;
+  constexpr int wsplit_min_m = 2048;
+  constexpr int wsplit_max_s = 8;
   if (p.M >= wsplit_min_m) {
     // M >= 2048 (the 8x8 and 16x16 levels): 2..8 slices of the WIDE tiles when K is long (3x3 convs, ff-out: K >= 4096) and
     // the tiles alone leave half the CUs idle; shorter K: no split at all.  (Round 3, one call, same box: the 8x8 convs on
@@ -1470,7 +1284,7 @@ static int gemm2_split(const anip_gemm_params& p, int* cfg) {
   const int64_t tiles = (int64_t)((p.M + 127) / 128) * ((p.N + bn - 1) / bn);
   if (tiles * 2 < 128 || tiles >= 320) return 1;
   const int nk = (p.K + 31) / 32;
-  static const int mink = getenv("ANIP_GEMM2_SPLIT_MINK") ? max(1, atoi(getenv("ANIP_GEMM2_SPLIT_MINK"))) : 16;   // experiments
+  constexpr int mink = 16;
   int S = (int)min((int64_t)8, (512 + tiles - 1) / tiles);
   S = min(S, nk / mink);                     // slices at least 512 deep
   if (S < 2) return 1;
@@ -1537,7 +1351,6 @@ int anip_gemm2_try(const anip_gemm_params& p, hipStream_t stream) {
   if (p.batch > 1 && (p.strideO & 7) != 0) return 0;
   const int64_t nb = p.batch > 1 ? p.batch : 1;
   const int64_t mt256 = (p.M + 255) / 256;
-  static const int force = getenv("ANIP_GEMM2_CFG") ? atoi(getenv("ANIP_GEMM2_CFG")) : 0;  // experiments: 1 = never wide, 2 = wide for any K
 
   // wide tiles (256 x 320 / 256 x 256, BK = 64): every K-tile inside one conv tap / one A source, N padded < 15 %,
   // and K long enough that the main loop (not the per-tile prologue / epilogue, where two resident blocks per CU
@@ -1547,7 +1360,7 @@ int anip_gemm2_try(const anip_gemm_params& p, hipStream_t stream) {
   // 307 -> 272 us, temporal qkv 122 -> 107, out-proj 59.9 -> 54.0; K = 320 layers no better, some worse)
   // (with the 64-B aligned tile deal the wide tiles also win on the K = 320 layers whose output is at least two of
   // their tiles wide — temporal qkv N = 960: 181 -> 155 us — but not on the N = 320 residual layers: 62 vs 66 us)
-  if (k64 && force != 1 && (p.K >= 640 || (p.K >= 256 && p.N >= 640) || force == 2)) {
+  if (k64 && (p.K >= 640 || (p.K >= 256 && p.N >= 640))) {
     const int64_t pad320 = (int64_t)((p.N + 319) / 320) * 320, pad256 = (int64_t)((p.N + 255) / 256) * 256;
     int wbn = 0;
     // (LayerNorm fold: the 256 x 256 and the 128-row instantiations take its accumulator transform without spilling; the
@@ -1555,7 +1368,7 @@ int anip_gemm2_try(const anip_gemm_params& p, hipStream_t stream) {
     if (p.act == 1 || p.ln_stats != nullptr) wbn = (pad256 * 100 <= (int64_t)p.N * 115) ? 256 : 0;   // GEGLU pairs tiles: even count per wave
     else if (pad320 <= pad256 && pad320 * 100 <= (int64_t)p.N * 115) wbn = 320;
     else if (pad256 * 100 <= (int64_t)p.N * 115) wbn = 256;
-    static const int wide_min = getenv("ANIP_GEMM2_WIDE_MIN") ? atoi(getenv("ANIP_GEMM2_WIDE_MIN")) : 192;   // experiments
+    constexpr int wide_min = 192;
     if (wbn != 0 && mt256 * ((p.N + wbn - 1) / wbn) * nb >= wide_min)      // >= 3/4 of the CUs busy
       return wbn == 320 ? dispatch_gemm2<256, 320, 8, 4, 64, 2>(p, stream) : dispatch_gemm2<256, 256, 8, 4, 64, 2>(p, stream);
   }
@@ -1566,7 +1379,7 @@ int anip_gemm2_try(const anip_gemm_params& p, hipStream_t stream) {
   }
   const int64_t tiles256 = mt256 * ((p.N + bn - 1) / bn) * nb;
   if (tiles256 * 2 < 128) return 0;
-  static const int big_min = getenv("ANIP_GEMM2_BIG_MIN") ? atoi(getenv("ANIP_GEMM2_BIG_MIN")) : 1024;   // experiments
+  constexpr int big_min = 1024;
   const bool big = tiles256 >= big_min && p.ln_stats == nullptr;   // >= 2 full rounds of 2 x 256 resident 256-row blocks
   if (big) return bn == 128 ? dispatch_gemm2<256, 128, 8, 2, 32, 3>(p, stream) : dispatch_gemm2<256, 160, 8, 2, 32, 3>(p, stream);
   // At most one 128-row tile per CU (the 8x8 level, M = 2048): 64-deep K-tiles and EIGHT waves per tile (wave tile 32 x 64 /
@@ -1574,10 +1387,9 @@ int anip_gemm2_try(const anip_gemm_params& p, hipStream_t stream) {
   // fragments, run its MFMAs — not by LDS space (96 / 108 KB: one block per CU) and not by the ring depth (a 4-stage ring:
   // no change).  Round 3, A/B inside one call each: M = 2048, N = K = 1280 25.6 us (4 waves, 32-deep) -> 22.1 (64-deep) ->
   // 19.1 (8 waves); the 2560 -> 1280 shortcut 42.2 -> 35.0 -> 30.9 us.  With 512 tiles (M = 8192: two to three blocks per
-  // CU on the 32-deep tiles) the 64-deep tiles lose: 50.6 -> 61.8 us.  ANIP_GEMM2_SMALL_BK64=0: never.
-  static const int small_bk64 = getenv("ANIP_GEMM2_SMALL_BK64") ? atoi(getenv("ANIP_GEMM2_SMALL_BK64")) : 1;
+  // CU on the 32-deep tiles) the 64-deep tiles lose: 50.6 -> 61.8 us.
   const int64_t tiles128 = (int64_t)((p.M + 127) / 128) * ((p.N + bn - 1) / bn) * nb;
-  if (small_bk64 && k64 && p.K >= 512 && tiles128 <= 256)
+  if (k64 && p.K >= 512 && tiles128 <= 256)
     return bn == 128 ? dispatch_gemm2<128, 128, 8, 2, 64, 3>(p, stream) : dispatch_gemm2<128, 160, 8, 2, 64, 3>(p, stream);
   return bn == 128 ? dispatch_gemm2<128, 128, 4, 2, 32, 3>(p, stream) : dispatch_gemm2<128, 160, 4, 2, 32, 3>(p, stream);
 }

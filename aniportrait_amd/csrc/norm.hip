@@ -476,9 +476,8 @@ extern "C" int64_t anip_groupnorm_ws_floats(int N, int64_t HW, int C, int G) {
 // Single-launch form for the 8x8 / 16x16 levels (measured on MI355X, 32 frames, stats + apply vs one slab kernel:
 // 16x16 C1280 27.8 -> 18.7 us, C2560 46.7 -> 31.5, 8x8 C1280 19.3 -> 14.6, C2560 29.9 -> 15.6; from 32x32 up the slab's
 // narrow row segments (cpg * 2 = 20 .. 120 B) lose to the two coalesced passes: 64x64 C320 57 -> 147 us).
-// ANIP_GN_SLAB_HW overrides the row limit (0 disables).
 extern "C" int anip_groupnorm_single_launch(int N, int64_t HW, int C, int G) {
-  static const int slab_hw = getenv("ANIP_GN_SLAB_HW") ? atoi(getenv("ANIP_GN_SLAB_HW")) : 256;
+  constexpr int slab_hw = 256;
   if (G <= 0 || C % G != 0) return 0;
   const int cpg = C / G;
   return (slab_hw > 0 && HW <= slab_hw && cpg <= 256 && (cpg & 1) == 0 && (int64_t)N * G >= 256) ? 1 : 0;
@@ -534,7 +533,7 @@ extern "C" int anip_groupnorm_frames(const void* x1, int C1, const void* x2, int
   }
   ANIP_LAUNCH_CHECK("anip_groupnorm(stats)");
   // apply: ~2048 pixels*C/8 vectors per block at least, >= 1024 blocks when possible
-  static const int apply_blocks = getenv("ANIP_GN_APPLY_BLOCKS") ? atoi(getenv("ANIP_GN_APPLY_BLOCKS")) : 1024;  // experiments
+  constexpr int apply_blocks = 1024;
   int64_t want = (apply_blocks + N - 1) / N;
   int64_t maxc = (HW + 15) / 16;
   int64_t ac = want < maxc ? want : maxc;

@@ -78,14 +78,8 @@ class _DenoiseRunner:
         self.pose = None if pose is None else [torch.empty_like(p) for p in pose]
         self.graph = None
         self.pred = None
-        # ANIP_CFG_STREAMS=1 (experiment): the two CFG halves of a step — independent networks on independent frames — as
-        # two forwards on two streams inside the one captured graph, so that one half's HBM-bound glue (GroupNorm,
-        # LayerNorm, K = 320 projections) and launch gaps run under the other half's MFMA-bound convolutions / FFN
-        self.split = S == 2 and os.environ.get("ANIP_CFG_STREAMS", "0") == "1"
-        if self.split:
-            self.side = torch.cuda.Stream(device=dev)
-            self.ridx = ((torch.full((f,), -1, dtype=torch.int32, device=dev), 0),
-                         (torch.full((f,), 1, dtype=torch.int32, device=dev), f))
+        # (the two CFG halves of a step as two forwards on two streams inside the graph measured 6 % slower, round 3: half-size
+        #  launches lose more than the overlap of HBM-bound and MFMA-bound kernels returns)
 
     def matches(self, x, ehs, pose):
         return (tuple(self.x.shape[1:]) == tuple(x.shape[1:]) and self.ehs.shape == ehs.shape and
@@ -96,9 +90,6 @@ class _DenoiseRunner:
         """new clip: CLIP token into the static buffer, reference-bank projections / attn2 vectors refreshed in place"""
         self.ehs.copy_(ehs)
         self.unet.prepare_reference(self.ehs)
-        if self.split:
-            for half in (0, 1):
-                self.unet.prepare_reference(self.ehs[half:half + 1], attn2_slot=1 + half)
 
     def set_pose(self, pose):
         if pose is not None:
@@ -110,26 +101,8 @@ class _DenoiseRunner:
             self.x[s_ * self.f:(s_ + 1) * self.f].copy_(x)
 
     def _forward(self):
-        if not self.split:
-            return self.unet.forward_nhwc(self.x, self.S, self.f, None, self.ehs, self.pose, temb_in=self.temb,
-                                          attn2_refresh=False)
-        f = self.f
-
-        def half(i):
-            sl = slice(i * f, (i + 1) * f)
-            return self.unet.forward_nhwc(self.x[sl], 1, f, None, self.ehs[i:i + 1],
-                                          None if self.pose is None else [p_[sl] for p_ in self.pose],
-                                          temb_in=self.temb[i:i + 1], attn2_refresh=False, ref_index=self.ridx[i],
-                                          attn2_slot=1 + i)
-
-        cur = torch.cuda.current_stream()
-        self.side.wait_stream(cur)
-        with torch.cuda.stream(self.side):
-            pu = half(0)
-        pc = half(1)
-        cur.wait_stream(self.side)
-        pu.record_stream(cur)
-        return torch.cat([pu, pc], dim=0)
+        return self.unet.forward_nhwc(self.x, self.S, self.f, None, self.ehs, self.pose, temb_in=self.temb,
+                                      attn2_refresh=False)
 
     def eager(self, x, temb):
         """un-captured forward (profilers / ANIP_NO_GRAPH): same static buffers, same in-place reference state"""

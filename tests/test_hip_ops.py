@@ -875,8 +875,7 @@ def test_ffn_geglu_fused(M):
 
 
 # ------------------------------------------------------------------------------------------------
-# wide tiles (256 x {256,320} x 64, one block per CU): the quarter-phased main loop of round 3 (ANIP_GEMM2_SCHED=1,
-# default; =0 selects round 2's loop) with every A loader (plain, two-source, 3x3 window, stride 2, fused upsample),
+# wide tiles (256 x {256,320} x 64, one block per CU): the quarter-phased main loop of round 3 with every A loader (plain, two-source, 3x3 window, stride 2, fused upsample),
 # every epilogue, ragged M / N / K tails, short and odd K-tile counts, and a repeated-run race screen (the schedule
 # keeps LDS-DMA in flight across barriers with counted vmcnt: a misplaced wait shows as rare wrong tiles)
 # ------------------------------------------------------------------------------------------------
@@ -967,7 +966,7 @@ def test_gemm2_wide_conv3x3(N, H, W, Cin, Cout, stride, pad, pad_hi, up):
 
 
 def test_gemm2_persistent_walk_shapes():
-    """more wide tiles than CUs (the persistent walk of launch_gemm2 when ANIP_GEMM2_PERSIST is on: a workgroup runs tiles
+    """more wide tiles than CUs (the persistent walk of launch_gemm2: a workgroup runs tiles
     blockIdx.x, + gridDim.x, ... and stages the next tile's first K-tile in front of its epilogue): tile counts that are
     not multiples of the CU count or of 8, every A loader, per-tile bias / row-group bias, residual; repeated runs must
     be bit-identical (the walk keeps LDS-DMA in flight across the epilogue)."""
@@ -1026,8 +1025,7 @@ def test_gemm2_persistent_walk_shapes():
 
 def test_gemm_residual_256x160_tiles():
     """the N = K = 320 residual layers of the 64x64 level (256 x 160 x 32 tiles, two workgroups per CU): bias + row-group
-    bias + residual through the full-line epilogue; run-to-run identical.  (Also the shape of the LDS-staged residual
-    experiment, ANIP_GEMM2_DBG=64.)"""
+    bias + residual through the full-line epilogue; run-to-run identical."""
     ops = _ops()
     M, N, K = 131072, 320, 320
     A = rnd(M, K, seed=501).to(DEV)

@@ -136,8 +136,8 @@ def bench_temporal(B, F, T, heads, d, tag):
 
 def main():
     """--only gemm,conv,attn,norm   restrict the families;   --cold   cache-cold launches (see _flush);   env switches of the library (read once per process) make
-    one invocation = one kernel variant: ANIP_GEMM2_DBG=8 (round-1 epilogue), ANIP_GEMM2_CFG=1|2 (never / always the
-    wide tiles), ANIP_ATTN_QH=1|2 (query groups per wave)."""
+    one invocation = one kernel variant: ANIP_ATTN_DMA=0 / ANIP_TEMPORAL_MFMA=0 (the first-generation attention kernels),
+    ANIP_LIB=<experiment build>; OPERANDS_ZERO=1 / ATTN_ZERO=1: all-zero operands (clock / power check)."""
     import os
     global COLD
     only = None

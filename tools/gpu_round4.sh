@@ -2,8 +2,6 @@
 # round-4 GPU session driver (grown from tools/gpu_round4.sh) (one gpurun call = one invocation): `bash tools/gpu_round4.sh <tag> <step> [<step> ...]`,
 # steps run in the order given:
 #   parity       fixture-based real-width parity tests (C2 4 steps / C5 768 / L=40 windows)
-#   ktests<S>    kernel unit tests of the GEMM / conv family with ANIP_GEMM2_SCHED=<S> (0: round-2 loop, 1: quarter-phased)
-#   kbench<S>    tools/bench_kernels.py gemm,conv with ANIP_GEMM2_SCHED=<S>;  kcmp prints the 0-vs-1 table
 #   bisect       per-block error table hip vs fp32 oracle at 32x32 / 64x64 latents (tests/bisect_parity.py)
 #   bench        the headline bench line (+ per-shape table);  bench2: a second run (cpu_baseline reproducibility)
 #   rocprof      rocprofv3 --kernel-trace --stats of the bench command
@@ -105,30 +103,6 @@ PY
   parity)
     timeout 900 python -m pytest tests/test_gpu_real_width.py -m gpu -q -s -k "fixture" > $OUT/parity_fixtures.log 2>&1; echo "rc=$?" >> $OUT/parity_fixtures.log
     grep -E "PSNR|passed|failed|rror|rc=" $OUT/parity_fixtures.log | tail -n 12 ;;
-  ktests0|ktests1)
-    S=${STEP#ktests}
-    ANIP_GEMM2_SCHED=$S timeout 900 python -m pytest tests/test_hip_ops.py -m gpu -q -k "gemm or conv3x3 or ffn" > $OUT/ktests_sched$S.log 2>&1; echo "rc=$?" >> $OUT/ktests_sched$S.log
-    grep -E "^FAILED|^ERROR|passed|failed|rc=" $OUT/ktests_sched$S.log | tail -n 25 ;;
-  kbench0|kbench1)
-    S=${STEP#kbench}
-    ANIP_GEMM2_SCHED=$S timeout 400 python tools/bench_kernels.py --only=gemm,conv > $OUT/kbench_sched$S.jsonl 2>&1; echo "rc=$?" ;;
-  kcmp)
-    python - <<PY
-import json
-def load(p):
-    d={}
-    try:
-        for l in open(p):
-            try: r=json.loads(l)
-            except Exception: continue
-            if "tag" in r: d[(r["kernel"],r["tag"])]=r
-    except FileNotFoundError: pass
-    return d
-a,b=load("$OUT/kbench_sched0.jsonl"),load("$OUT/kbench_sched1.jsonl")
-for k in a:
-    if k in b: print("%-8s %-38s s0 %8.1f us %7.1f TF | s1 %8.1f us %7.1f TF | x%.3f"%(k[0],k[1],a[k]["us"],a[k]["tflops"],b[k]["us"],b[k]["tflops"],a[k]["us"]/b[k]["us"]))
-PY
-    ;;
   bisect)
     timeout 900 python tests/bisect_parity.py --sizes 32 64 --frames 2 --backends hip --out $OUT/bisect_hip.json > $OUT/bisect_hip.log 2>&1; echo "rc=$?" >> $OUT/bisect_hip.log
     grep -E "conv_out rel|rc=" $OUT/bisect_hip.log | tail -n 6 ;;
