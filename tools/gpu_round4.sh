@@ -113,6 +113,10 @@ PY
     timeout 900 python bench.py --table-dir $OUT > $OUT/$STEP.log 2>&1; echo "bench rc=$?" | tee -a $OUT/$STEP.log
     grep -o '"value": [0-9.]*' $OUT/$STEP.log | head -1
     grep -o '"cpu_baseline": {[^}]*}' $OUT/$STEP.log | cut -c1-300 ;;
+  qbench:*)   # qbench:<name> — short bench (no cpu baseline, no roofline) under the current environment
+    N=${STEP#qbench:}
+    timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline > $OUT/qbench_$N.log 2>&1; echo "rc=$?"
+    grep -o '"value": [0-9.]*' $OUT/qbench_$N.log | head -1; grep -o '"ms_per_step": [0-9.]*' $OUT/qbench_$N.log | head -1 ;;
   benchx)
     timeout 1200 python bench.py --extra-configs --table-dir $OUT > $OUT/benchx.log 2>&1; echo "bench rc=$?" | tee -a $OUT/benchx.log
     grep -o '"value": [0-9.]*' $OUT/benchx.log | head -1 ;;
