@@ -1359,8 +1359,10 @@ int anip_gemm2_try(const anip_gemm_params& p, hipStream_t stream) {
   // (round 2 microbench, 32 frames: K = 640 layers of the 32x32 level 10-12 % faster on the wide tiles — ff-in GEGLU
   // 307 -> 272 us, temporal qkv 122 -> 107, out-proj 59.9 -> 54.0; K = 320 layers no better, some worse)
   // (with the 64-B aligned tile deal the wide tiles also win on the K = 320 layers whose output is at least two of
-  // their tiles wide — temporal qkv N = 960: 181 -> 155 us — but not on the N = 320 residual layers: 62 vs 66 us)
-  if (k64 && (p.K >= 640 || (p.K >= 256 && p.N >= 640))) {
+  // their tiles wide — temporal qkv N = 960: 181 -> 155 us; round 4, with the persistent walk and the whole-line epilogue in:
+  // the N = K = 320 layers of the 64x64 level, too — warm the same, cache-cold 97-107 -> 91 us (+ residual), 68 -> 60, 65 -> 58;
+  // whole clip 1302.5 -> 1298.4 ms in one call, profiles/r04/w_*)
+  if (k64 && (p.K >= 640 || (p.K >= 256 && p.N >= 320))) {
     const int64_t pad320 = (int64_t)((p.N + 319) / 320) * 320, pad256 = (int64_t)((p.N + 255) / 256) * 256;
     int wbn = 0;
     // (LayerNorm fold: the 256 x 256 and the 128-row instantiations take its accumulator transform without spilling; the
@@ -1391,5 +1393,8 @@ int anip_gemm2_try(const anip_gemm_params& p, hipStream_t stream) {
   const int64_t tiles128 = (int64_t)((p.M + 127) / 128) * ((p.N + bn - 1) / bn) * nb;
   if (k64 && p.K >= 512 && tiles128 <= 256)
     return bn == 128 ? dispatch_gemm2<128, 128, 8, 2, 64, 3>(p, stream) : dispatch_gemm2<128, 160, 8, 2, 64, 3>(p, stream);
+  // N a multiple of both widths (1280 at the 16x16 level): the 160-wide tiles — 512 of them instead of 640, wave tile 64 x 80
+  // (round 4, one call: M = 8192, N = K = 1280 + residual 52 / 66 us warm / cold -> 39 / 57; whole clip 1338.0 -> 1302.5 ms)
+  if (bn == 128 && p.act != 1 && p.N % 160 == 0) bn = 160;
   return bn == 128 ? dispatch_gemm2<128, 128, 4, 2, 32, 3>(p, stream) : dispatch_gemm2<128, 160, 4, 2, 32, 3>(p, stream);
 }

@@ -14,6 +14,7 @@ DEV = "cuda"
 
 
 COLD = False          # --cold: evict the Infinity Cache / L2 before every timed launch
+BOTH = False          # --both: GEMM rows carry the warm time (us) and the cache-cold time (us_cold)
 _FLUSH = None
 
 
@@ -70,11 +71,18 @@ def bench_gemm(M, N, K, tag, res=False, rb=False, geglu=False, a2=0, trans=False
     n_out = N // 2 if geglu else N
     R = r16(M, n_out) if res else None
     RB = torch.randn((M // 4096 if M >= 4096 else 1, n_out), device=DEV) if rb else None
-    t = timeit(lambda: ops.gemm(A, W, b, A2=A2, residual=R, rowbias=RB, rows_per_group=4096 if M >= 4096 else M,
-                                act=1 if geglu else 0, trans_out=trans))
+    fn = lambda: ops.gemm(A, W, b, A2=A2, residual=R, rowbias=RB, rows_per_group=4096 if M >= 4096 else M,  # noqa: E731
+                          act=1 if geglu else 0, trans_out=trans)
+    t = timeit(fn)
+    t_cold = None
+    if BOTH:
+        global COLD
+        COLD = True
+        t_cold = timeit(fn) * 1e6
+        COLD = False
     by = 2 * (A.numel() + (A2.numel() if a2 else 0) + W.numel() + M * n_out * (2 if res else 1))
     print(json.dumps(dict(kernel="gemm", tag=tag, M=M, N=N, K=K, res=res, rb=rb, geglu=geglu, a2=a2, trans=trans,
-                          us=t * 1e6, tflops=2 * M * N * K / t / 1e12, gbps=by / t / 1e9)), flush=True)
+                          us=t * 1e6, tflops=2 * M * N * K / t / 1e12, gbps=by / t / 1e9, us_cold=t_cold)), flush=True)
 
 
 def bench_conv(N, H, Cin, Cout, tag, up=False, stride=1, res=False, rb=False, pad=1, pad_hi=None):
@@ -139,13 +147,15 @@ def main():
     one invocation = one kernel variant: ANIP_ATTN_DMA=0 / ANIP_TEMPORAL_MFMA=0 (the first-generation attention kernels),
     ANIP_LIB=<experiment build>; OPERANDS_ZERO=1 / ATTN_ZERO=1: all-zero operands (clock / power check)."""
     import os
-    global COLD
+    global COLD, BOTH
     only = None
     for a in sys.argv[1:]:
         if a.startswith("--only"):
             only = set(a.split("=", 1)[1].split(","))
         if a == "--cold":
             COLD = True
+        if a == "--both":      # GEMM rows: warm loop in `us`, cache-cold launches in `us_cold`
+            BOTH = True
     want = lambda k: only is None or k in only  # noqa: E731
     print(json.dumps(dict(device=ops.device_info(), cold=COLD,
                           env={k: v for k, v in os.environ.items() if k.startswith("ANIP_")})), flush=True)
@@ -169,7 +179,11 @@ def main():
         bench_gemm(NF * 256, 3840, 1280, "16^2 temporal qkv x2")
         bench_gemm(NF * 256, 10240, 1280, "16^2 ff-in geglu x2", geglu=True)
         bench_gemm(NF * 256, 1280, 5120, "16^2 ff-out x2", res=True)
+        bench_gemm(NF * 256, 1280, 1280, "16^2 proj_in / to_q", )
+        bench_gemm(NF * 256, 1280, 1280, "16^2 to_v^T", trans=True)
         bench_gemm(NF * 64, 1280, 1280, "8^2 out-proj", res=True)
+        bench_gemm(NF * 64, 1280, 1280, "8^2 proj_in / to_q")
+        bench_gemm(NF * 64, 3840, 1280, "8^2 temporal qkv")
         bench_gemm(NF * 64, 1280, 2560, "8^2 shortcut 2560->1280 (concat)", a2=1280)
         bench_gemm(NF * 64, 10240, 1280, "8^2 ff-in geglu", geglu=True)
         bench_gemm(NF * 64, 1280, 5120, "8^2 ff-out", res=True)
