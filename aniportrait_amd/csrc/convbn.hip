@@ -115,6 +115,94 @@ __global__ __launch_bounds__(NT) void conv_direct_kernel(const f16* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------
+// conv_in of the UNets (4 latent channels -> 320, 3x3, stride 1, pad 1, + fused pose-feature add): the generic kernel above
+// walks the taps with a data-dependent `continue` per tap, so its nine 8-B input loads are issued and waited for one
+// after the other, and decodes the pixel with 64-bit divisions — 210 us for 84 MB of output + 84 MB of pose features
+// (0.8 TB/s); with the loads batched and 32-bit indices it was still VALU-bound at 137 us: 288 f16 -> f32 conversions + 288
+// FMAs per item.  Here the nine loads of an item are in flight together (out-of-image taps read as zero), the index
+// arithmetic is 32-bit, a block keeps its 23 KB of weights for 16 items per thread, and the 36-deep contraction runs as 18
+// v_dot2_f32_f16 per output channel (exact fp16 products, fp32 accumulation; rounding differs from the generic kernel's
+// sequential fp32 FMAs in the last bit of the fp32 sum).
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void conv3x3_c4_kernel(const f16* __restrict__ x, const f16* __restrict__ wp,
+                                                       const float* __restrict__ bias, const f16* __restrict__ res,
+                                                       f16* __restrict__ y, int N, int H, int W, int Cout, int pix_per_block,
+                                                       int relu) {
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  // LDS image: [9 taps][2 channel pairs][Cout] half2 = {w[tap][2 pr][co], w[tap][2 pr + 1][co]}: one v_dot2_f32_f16 per
+  // (tap, pair, output channel) — fp16 products, fp32 accumulate, no conversion instructions
+  extern __shared__ __attribute__((aligned(16))) f16 sw[];
+  const int tid = threadIdx.x;
+  const int cg_n = Cout >> 3;
+  for (int i = tid; i < 36 * cg_n; i += NT) {
+    const int k = i / cg_n, cgi = i - k * cg_n;      // k = tap * 4 + ci
+    U4H8 v;
+    v.u = ((const u32x4*)wp)[i];
+    f16* dst = sw + ((((k >> 2) * 2 + ((k >> 1) & 1)) * Cout + cgi * 8) * 2 + (k & 1));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[e * 2] = v.e[e];
+  }
+  __syncthreads();
+  const int npix = N * H * W;
+  const int pix0 = blockIdx.x * pix_per_block;
+  const int nitems = min(pix_per_block, npix - pix0) * cg_n;
+  for (int o = tid; o < nitems; o += NT) {
+    const int pl = o / cg_n, cg = o - pl * cg_n;
+    const int pix = pix0 + pl;
+    const int ox = pix % W;
+    const int t = pix / W;
+    const int oy = t % H;
+    const int img = t / H;
+    const int co0 = cg * 8;
+    union X4 { u32x2 u; h2 p[2]; };
+    X4 xv[9];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+      const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+      xv[tap].u = u32x2{0u, 0u};                      // out-of-image taps contribute exact zeros
+      if (in) xv[tap].u = *(const u32x2*)(x + ((int64_t)(img * H + iy) * W + ix) * 4);
+    }
+    float acc[8];
+    if (bias != nullptr) {
+      const float4 b0 = *(const float4*)(bias + co0), b1 = *(const float4*)(bias + co0 + 4);
+      acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w;
+      acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    }
+    U4H8 rv;
+    rv.u = u32x4{0u, 0u, 0u, 0u};
+    if (res != nullptr) rv.u = *(const u32x4*)(res + (int64_t)pix * Cout + co0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        union { u32x4 u[2]; h2 p[8]; } wv;
+        const u32x4* wsrc = (const u32x4*)(sw + ((tap * 2 + pr) * Cout + co0) * 2);
+        wv.u[0] = wsrc[0];
+        wv.u[1] = wsrc[1];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = __builtin_amdgcn_fdot2(xv[tap].p[pr], wv.p[e], acc[e], false);
+      }
+    }
+    if (res != nullptr) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += (float)rv.e[e];
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] = fmaxf(acc[e], 0.f);
+    }
+    U4H8 ov;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ov.e[e] = (f16)acc[e];
+    *(u32x4*)(y + (int64_t)pix * Cout + co0) = ov.u;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // BatchNorm pass 1: per-block partial (sum, sumsq) per channel over a chunk of rows of x [M][C].
 // part[(blk * C + c) * 2 + {0,1}]
 // ---------------------------------------------------------------------------------------------------
@@ -272,6 +360,19 @@ extern "C" int anip_conv_direct(const void* x, const void* wp, const float* bias
   const int Ho = (H + 2 * pad - ksize) / stride + 1, Wo = (W + 2 * pad - ksize) / stride + 1;
   ANIP_REQUIRE(Ho > 0 && Wo > 0, "anip_conv_direct: empty output");
   const int cg_n = Cout8 >> 3;
+  if (ksize == 3 && Cin == 4 && stride == 1 && pad == 1 && (Cout & 7) == 0 && (((uintptr_t)bias) & 15) == 0 &&
+      (int64_t)N * H * W * (int64_t)(Cout >> 3) < (1ll << 31)) {
+    int ppb4 = (NT * 16) / cg_n;   // ~16 (pixel, channel-group) items per thread
+    if (ppb4 < 1) ppb4 = 1;
+    const int64_t blocks4 = cdiv64((int64_t)N * H * W, ppb4);
+    {
+      AnipProfScope prof_(ANIP_K_CONV_SMALL, (void*)stream);
+      hipLaunchKernelGGL(conv3x3_c4_kernel, dim3((unsigned)blocks4), dim3(NT), lds, (hipStream_t)stream, (const f16*)x,
+                         (const f16*)wp, bias, (const f16*)residual, (f16*)y, N, H, W, Cout, ppb4, relu);
+    }
+    ANIP_LAUNCH_CHECK("anip_conv_direct(c4)");
+    return 0;
+  }
   int ppb = (NT * 4) / cg_n;  // ~4 (pixel, channel-group) items per thread
   if (ppb < 1) ppb = 1;
   const int64_t npix = (int64_t)N * Ho * Wo;

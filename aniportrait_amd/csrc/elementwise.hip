@@ -65,37 +65,60 @@ __global__ __launch_bounds__(NT) void conv_small_kernel(const f16* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// y[m][n] = sum_k f(x[m][k]) W[n][k] + b[n], M <= 16; one wave per output column n
+// y[m][n] = sum_k f(x[m][k]) W[n][k] + b[n], M <= 16 (time-embedding MLP, the stacked time_emb_proj of all resnets,
+// collapsed attn2): a weight-streaming GEMV.  f(x) (SiLU or identity) is evaluated ONCE per block into LDS — round 4:
+// the first version applied it per output column, 51 M exp + rcp for the stacked projection (N = 20160, K = 1280, M = 2:
+// 102 us = 0.5 TB/s of weight traffic) — and a wave walks LS_COLS columns with all their 16-B weight loads of a K-step in
+// flight.  One block = 4 waves = 4 * LS_COLS columns.
 // ---------------------------------------------------------------------------------------------
+constexpr int LS_COLS = 4;
+template <int MT>
 __global__ __launch_bounds__(NT) void linear_small_kernel(const float* __restrict__ x, const f16* __restrict__ W,
                                                          const float* __restrict__ bias, float* __restrict__ y, int M,
                                                          int N, int K, int silu_in) {
+  extern __shared__ __attribute__((aligned(16))) float sx[];   // [M][K]
   const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
-  if (n >= N) return;
-  float acc[16];
+  for (int i = threadIdx.x; i < M * K; i += NT) {
+    float xv = x[i];
+    if (silu_in) xv = silu_f(xv);
+    sx[i] = xv;
+  }
+  __syncthreads();
+  const int n0 = (blockIdx.x * (NT / 64) + (threadIdx.x >> 6)) * LS_COLS;
+  if (n0 >= N) return;
+  float acc[LS_COLS][MT];
 #pragma unroll
-  for (int m = 0; m < 16; ++m) acc[m] = 0.f;
+  for (int j = 0; j < LS_COLS; ++j)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[j][m] = 0.f;
   for (int k = lane * 8; k < K; k += 64 * 8) {
-    U4H8 wv;
-    wv.u = *(const u32x4*)(W + (int64_t)n * K + k);
+    U4H8 wv[LS_COLS];
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
+    for (int j = 0; j < LS_COLS; ++j) {
+      const int n = min(n0 + j, N - 1);
+      wv[j].u = *(const u32x4*)(W + (int64_t)n * K + k);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
       if (m < M) {
+        const float4 xa = *(const float4*)(sx + m * K + k), xb = *(const float4*)(sx + m * K + k + 4);
+        const float xs[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float xv = x[(int64_t)m * K + k + e];
-          if (silu_in) xv = silu_f(xv);
-          acc[m] += xv * (float)wv.e[e];
-        }
+        for (int j = 0; j < LS_COLS; ++j)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[j][m] += xs[e] * (float)wv[j].e[e];
       }
     }
   }
 #pragma unroll
-  for (int m = 0; m < 16; ++m) {
-    if (m < M) {
-      const float s = wave_sum(acc[m]);
-      if (lane == 0) y[(int64_t)m * N + n] = s + (bias ? bias[n] : 0.f);
+  for (int j = 0; j < LS_COLS; ++j) {
+    const int n = n0 + j;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      if (m < M) {
+        const float s_ = wave_sum(acc[j][m]);
+        if (lane == 0 && n < N) y[(int64_t)m * N + n] = s_ + (bias ? bias[n] : 0.f);
+      }
     }
   }
 }
@@ -281,11 +304,21 @@ extern "C" int anip_linear_small(const float* x, const void* W, const float* bia
   ANIP_REQUIRE(x && W && y, "anip_linear_small: null pointer");
   ANIP_REQUIRE(M >= 1 && M <= 16, "anip_linear_small: M=%d must be in [1,16]", M);
   ANIP_REQUIRE((K & 7) == 0, "anip_linear_small: K=%d must be a multiple of 8", K);
-  const int blocks = (N + NT / 64 - 1) / (NT / 64);
+  const int cols_per_block = (NT / 64) * LS_COLS;
+  const int blocks = (N + cols_per_block - 1) / cols_per_block;
+  const size_t lds = (size_t)M * K * sizeof(float);
+  ANIP_REQUIRE(lds <= 65536, "anip_linear_small: M * K = %d * %d floats do not fit in 64 KB of LDS", M, K);
   {
     AnipProfScope prof_(ANIP_K_LINEAR_SMALL, (void*)stream);
-    hipLaunchKernelGGL(linear_small_kernel, dim3(blocks), dim3(NT), 0, (hipStream_t)stream, x, (const f16*)W, bias, y,
-                       M, N, K, silu_in);
+    if (M <= 2)
+      hipLaunchKernelGGL(linear_small_kernel<2>, dim3(blocks), dim3(NT), lds, (hipStream_t)stream, x, (const f16*)W, bias, y,
+                         M, N, K, silu_in);
+    else if (M <= 4)
+      hipLaunchKernelGGL(linear_small_kernel<4>, dim3(blocks), dim3(NT), lds, (hipStream_t)stream, x, (const f16*)W, bias, y,
+                         M, N, K, silu_in);
+    else
+      hipLaunchKernelGGL(linear_small_kernel<16>, dim3(blocks), dim3(NT), lds, (hipStream_t)stream, x, (const f16*)W, bias, y,
+                         M, N, K, silu_in);
   }
   ANIP_LAUNCH_CHECK("anip_linear_small");
   return 0;

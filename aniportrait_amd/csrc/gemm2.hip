@@ -1250,9 +1250,26 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // 128 / 160: 128-row 4-wave tiles of that width; 256 / 320: the wide 256-row tiles of that width
 static int gemm2_split(const anip_gemm_params& p, int* cfg) {
   if (p.ln_stats != nullptr) return 1;     // the reduce pass does not carry the LayerNorm fold
-  if (p.batch > 1 || p.act == 1 || p.trans_out || p.M < 1024 || p.M > 16384 || (p.N & 3) != 0) return 1;
+  if (p.batch > 1 || p.act == 1 || p.trans_out || p.M < 64 || p.M > 16384 || (p.N & 3) != 0) return 1;
   if (p.conv ? (p.Cin % 32 != 0) : (p.A2 != nullptr && (p.K1 % 32) != 0)) return 1;
   if ((((uintptr_t)p.bias | (uintptr_t)p.rowbias) & 15) != 0) return 1;
+  if (p.M < 1024) {
+    // A handful of 128-row tiles under a long K: the once-per-clip ReferenceNet at its 8x8 / 16x16 levels (M = 128 / 512 for
+    // the CFG pair of one reference frame; its 3x3 convolutions stream 29-59 MB of weights through 10 workgroups of the
+    // small-problem kernel: 270 / 530 us -> 30 / 36 us split, 16x16: 273 / 538 -> 48 / 80, profiles/r04/u_*).  Up to 32 slices, at least 256 deep, until the launch has one block per CU.
+    if (p.K < 1024) return 1;
+    const int64_t pad128 = (int64_t)((p.N + 127) / 128) * 128, pad160 = (int64_t)((p.N + 159) / 160) * 160;
+    const int bn = pad160 < pad128 ? 160 : 128;
+    const int64_t tiles = (int64_t)((p.M + 127) / 128) * ((p.N + bn - 1) / bn);
+    if (tiles > 96) return 1;
+    const int nk = (p.K + 31) / 32;
+    int S = (int)min((int64_t)32, (256 + tiles - 1) / tiles);
+    S = min(S, nk / 8);
+    if (S < 2) return 1;
+    *cfg = bn;
+    const int per = (nk + S - 1) / S;
+    return (nk + per - 1) / per;
+  }
   // experiment knobs: smallest M that takes the wide-tile split (default 2048: the 8x8 level), most slices (default 8)
   constexpr int wsplit_min_m = 2048;
   constexpr int wsplit_max_s = 8;

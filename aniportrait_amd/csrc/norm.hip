@@ -114,23 +114,41 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const f16* __restrict__ x1
   float* gmean = sm + 2 * C;
   float* grstd = gmean + G;
   const int cpg = C / G;
-  if (tid < G) {
+  {
     // fps = frames per statistic: 1 = per-frame GroupNorm (InflatedGroupNorm); f = plain nn.GroupNorm on the 5-D tensor
     // (src/models/resnet.py:161-164 with use_inflated_groupnorm=False, configs/inference/inference_v1.yaml): the
-    // statistics run over (C/G, f, H, W) of a sample — the per-(frame, chunk) partial sums of its f frames are added here
-    float S = 0.f, Q = 0.f;
+    // statistics run over (C/G, f, H, W) of a sample — the per-(frame, chunk) partial sums of its f frames are added here.
+    // NT / G threads share a group's partials (fixed strided order, then a fixed-order sum of the NT / G parts: still
+    // deterministic) — one or two frames come with up to 256 chunks, and 32 threads adding them one after the other cost
+    // every apply block of the ReferenceNet / VAE-encoder launches 60 us (round 4)
+    float* red = grstd + G;                     // [parts][G][2]
+    const int parts = NT / G;
+    const int part = tid / G, g = tid - part * G;
     const int n_first = (n / fps) * fps;
-    for (int fr = 0; fr < fps; ++fr)
-      for (int ch = 0; ch < nchunks; ++ch) {
-        const float* o = ws + (((int64_t)(n_first + fr) * nchunks + ch) * G + tid) * 2;
+    const int total = fps * nchunks;
+    if (part < parts) {
+      float S = 0.f, Q = 0.f;
+      for (int idx = part; idx < total; idx += parts) {
+        const float* o = ws + (((int64_t)n_first * nchunks + idx) * G + g) * 2;   // (frame, chunk) pairs are consecutive
         S += o[0];
         Q += o[1];
       }
-    const float cnt = (float)((double)HW * cpg * fps);
-    const float mean = S / cnt;
-    const float var = fmaxf(Q / cnt - mean * mean, 0.f);
-    gmean[tid] = mean;
-    grstd[tid] = rsqrtf(var + eps);
+      red[(part * G + g) * 2] = S;
+      red[(part * G + g) * 2 + 1] = Q;
+    }
+    __syncthreads();
+    if (tid < G) {
+      float S = 0.f, Q = 0.f;
+      for (int pt = 0; pt < parts; ++pt) {
+        S += red[(pt * G + tid) * 2];
+        Q += red[(pt * G + tid) * 2 + 1];
+      }
+      const float cnt = (float)((double)HW * cpg * fps);
+      const float mean = S / cnt;
+      const float var = fmaxf(Q / cnt - mean * mean, 0.f);
+      gmean[tid] = mean;
+      grstd[tid] = rsqrtf(var + eps);
+    }
   }
   __syncthreads();
   for (int c = tid; c < C; c += NT) {
@@ -540,7 +558,7 @@ extern "C" int anip_groupnorm_frames(const void* x1, int C1, const void* x2, int
   if (ac < 1) ac = 1;
   const int64_t ppa = (HW + ac - 1) / ac;
   const int achunks = (int)((HW + ppa - 1) / ppa);
-  const size_t sm2 = (size_t)(2 * C + 2 * G) * sizeof(float);
+  const size_t sm2 = (size_t)(2 * C + 2 * G + 2 * NT) * sizeof(float);   // scale, shift, mean, rstd, finalize partials
   {
     AnipProfScope prof_(ANIP_K_GN_APPLY, (void*)stream);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(achunks, N), dim3(NT), sm2, (hipStream_t)stream, (const f16*)x1, C1,

@@ -187,6 +187,10 @@ def main():
         bench_gemm(NF * 64, 1280, 2560, "8^2 shortcut 2560->1280 (concat)", a2=1280)
         bench_gemm(NF * 64, 10240, 1280, "8^2 ff-in geglu", geglu=True)
         bench_gemm(NF * 64, 1280, 5120, "8^2 ff-out", res=True)
+        bench_gemm(512, 1280, 1280, "refnet 16^2 out-proj", res=True)
+        bench_gemm(512, 1280, 5120, "refnet 16^2 ff-out", res=True)
+        bench_gemm(128, 1280, 1280, "refnet 8^2 out-proj", res=True)
+        bench_gemm(128, 1280, 2560, "refnet 8^2 shortcut (concat)", a2=1280)
         bench_gemm(8192, 8192, 8192, "square 8k")
     if want("conv"):
         bench_conv(NF, 64, 320, 320, "res 64^2 320 conv2", res=True)
@@ -197,6 +201,11 @@ def main():
         bench_conv(NF, 8, 1280, 1280, "res 8^2 1280 conv2", res=True)
         bench_conv(NF, 8, 2560, 1280, "res 8^2 2560->1280 conv1", rb=True)
         bench_conv(NF, 32, 640, 640, "up 32->64", up=True)
+        bench_conv(2, 8, 1280, 1280, "refnet 8^2 1280 conv2", res=True)
+        bench_conv(2, 8, 2560, 1280, "refnet 8^2 2560->1280 conv1", rb=True)
+        bench_conv(2, 16, 1280, 1280, "refnet 16^2 1280 conv2", res=True)
+        bench_conv(2, 16, 2560, 1280, "refnet 16^2 2560->1280 conv1", rb=True)
+        bench_conv(2, 32, 640, 640, "refnet 32^2 640 conv2", res=True)
         bench_conv(16, 256, 256, 256, "vae 256^2 256", res=True)
         bench_conv(16, 512, 128, 128, "vae 512^2 128", res=True)
         bench_conv(1, 256, 256, 256, "vae-enc 256^2 s2 pad(0,1)", stride=2, pad=0, pad_hi=1)
@@ -205,6 +214,25 @@ def main():
         bench_attn(NF, 1024, 8, 80, "32^2 d80")
         bench_attn(NF, 256, 8, 160, "16^2 d160")
         bench_attn(NF, 64, 8, 160, "8^2 d160")
+    if want("misc"):   # the small once-per-step / once-per-clip kernels
+        x = r16(NF, 64, 64, 4)
+        wp = ops.pack_conv_direct(r16(320, 4, 3, 3, scale=1 / 6.0))
+        b = torch.randn(320, device=DEV)
+        pose = r16(NF, 64, 64, 320)
+        t = timeit(lambda: ops.conv_direct(x, wp, b, 320, 3, residual=pose))
+        print(json.dumps(dict(kernel="conv_direct", tag="conv_in 4->320 64^2 + pose", us=t * 1e6,
+                              gbps=(x.numel() + 2 * pose.numel()) * 2 / t / 1e9)), flush=True)
+        xs = torch.randn(2, 1280, device=DEV)
+        Wt = r16(20160, 1280, scale=1280 ** -0.5)
+        bt = torch.randn(20160, device=DEV)
+        t = timeit(lambda: ops.linear_small(xs, Wt, bt, silu_in=True))
+        print(json.dumps(dict(kernel="linear_small", tag="stacked time_emb_proj M2 N20160 K1280", us=t * 1e6,
+                              gbps=Wt.numel() * 2 / t / 1e9)), flush=True)
+        for (n_, hw, c) in ((2, 4096, 320), (1, 4096, 512), (2, 1024, 640), (1, 262144, 128)):
+            xg = r16(n_, hw, c)
+            g_, b_ = torch.randn(c, device=DEV), torch.randn(c, device=DEV)
+            t = timeit(lambda: ops.groupnorm(xg, g_, b_, 32, 1e-5, silu=True))
+            print(json.dumps(dict(kernel="groupnorm", tag=f"N{n_} HW{hw} C{c}", us=t * 1e6, gbps=xg.numel() * 6 / t / 1e9)), flush=True)
     if want("norm"):
         bench_gn(NF, 4096, 320, "64^2 C320")
         bench_gn(NF, 4096, 640, "64^2 C640")

@@ -117,6 +117,9 @@ PY
     N=${STEP#qbench:}
     timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline > $OUT/qbench_$N.log 2>&1; echo "rc=$?"
     grep -o '"value": [0-9.]*' $OUT/qbench_$N.log | head -1; grep -o '"ms_per_step": [0-9.]*' $OUT/qbench_$N.log | head -1 ;;
+  mbench:*)   # mbench:<name> — the small once-per-step / once-per-clip kernels (tools/bench_kernels.py --only=misc)
+    N=${STEP#mbench:}
+    timeout 300 python tools/bench_kernels.py --only=misc > $OUT/mbench_$N.jsonl 2>&1; echo "rc=$?"; tail -n 8 $OUT/mbench_$N.jsonl | cut -c1-200 ;;
   benchx)
     timeout 1200 python bench.py --extra-configs --table-dir $OUT > $OUT/benchx.log 2>&1; echo "bench rc=$?" | tee -a $OUT/benchx.log
     grep -o '"value": [0-9.]*' $OUT/benchx.log | head -1 ;;
