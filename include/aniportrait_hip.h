@@ -191,6 +191,7 @@ int anip_softmax_rows(const float* s, void* p, int64_t rows, int cols, void* str
 
 /* ---- tiny dense layers (M <= 16 rows): time embedding MLP, time_emb_proj, collapsed attn2 -------
  * y[m][n] = sum_k f(x[m][k]) * W[n][k] + bias[n], f = SiLU if silu_in.  x,y fp32; W fp16.
+ * 1 <= M <= 16, K % 8 == 0, and f(x) is staged in LDS: M * K * 4 bytes <= 64 KB (error otherwise).
  * (src/models/unet_3d.py:463-469, src/models/resnet.py:226-227) */
 int anip_linear_small(const float* x, const void* W, const float* bias, float* y, int M, int N, int K,
                       int silu_in, void* stream);

@@ -42,7 +42,7 @@ def family(name):
     if "splitk_reduce" in name:
         return "gemm_kernel<false>"     # shared by the conv and the linear split-K; it carries no contraction
     for key, fam in (("ref_attn", "ref_attn_kernel"), ("temporal_attn", "temporal_attn_kernel"), ("gn_stats", "gn_stats_kernel"),
-                     ("gn_apply", "gn_apply_kernel"), ("gn_slab", "gn_apply_kernel"), ("layernorm_kernel", "layernorm_kernel"), ("softmax_rows", "softmax_rows_kernel"),
+                     ("gn_apply", "gn_apply_kernel"), ("gn_slab", "gn_apply_kernel"), ("layernorm_kernel", "layernorm_kernel"), ("row_stats", "layernorm_kernel"), ("softmax_rows", "softmax_rows_kernel"),
                      ("conv_direct", "conv_small_kernel"), ("conv3x3_c4", "conv_small_kernel"), ("conv_small", "conv_small_kernel"), ("linear_small", "linear_small_kernel"),
                      ("bn_", "batchnorm_kernels"), ("ffn_geglu", "gemm_kernel<false>")):
         if key in name:
