@@ -21,7 +21,7 @@ def _load(path, name):
 
 def test_pmc_summarize_knows_every_kernel_of_the_library():
     from aniportrait_amd import _lib
-    lib = _lib.lib_path() if hasattr(_lib, "lib_path") else os.path.join(ROOT, "aniportrait_amd", "lib", "libaniportrait_hip.so")
+    lib = _lib.LIB_PATH
     if not os.path.exists(lib):
         pytest.skip("library not built")
     out = subprocess.run(["nm", "-C", lib], capture_output=True, text=True, check=True).stdout
