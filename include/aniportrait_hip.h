@@ -94,7 +94,8 @@ typedef struct anip_gemm_params {
   int trans_out;                         /* 1: store the result transposed, out[n*ldo + m] (fp16; bias only):
                                             V^T = (x W_v^T)^T for anip_ref_attention */
   /* split-K for problems with too few output tiles to fill 256 CUs (the 8x8 / 16x16 levels: M = 2048, K up to
-   * 23040): anip_gemm_workspace_bytes(p) > 0 means anip_gemm wants that many bytes of device scratch in
+   * 23040; since round 4 also 64 <= M < 1024 under K >= 1024 — the ReferenceNet's M = 128 / 512 — with up to 32
+   * slices): anip_gemm_workspace_bytes(p) > 0 means anip_gemm wants that many bytes of device scratch in
    * `workspace` (fp32 partial tiles [split][M][N], reduced with the whole epilogue by a second kernel);
    * 0 means no workspace is needed.  The library never allocates. */
   void* workspace; int64_t workspace_bytes;

@@ -67,3 +67,40 @@ def test_hot_path_fails_loudly_without_gpu():
         m(torch.zeros(2, 4, 2, 8, 8), 10, torch.zeros(2, 1, 64))
     with pytest.raises(HipLibraryError):
         m.packed()
+
+
+def test_split_k_decision_is_host_logic_and_covers_the_small_m_problems():
+    """anip_gemm_workspace_bytes is pure host logic (no launch): which problems the library splits over K.
+    Round 4: the ReferenceNet's deep levels (M = 128 / 512 rows for the CFG pair of one reference frame, K = 11 520 ...
+    23 040 in its 3x3 convolutions) are split; short-K and chip-filling problems are not; the workspace is
+    [slices][M][N] fp32."""
+    import ctypes as C
+    from aniportrait_amd import _lib
+    lib = _lib.load()
+
+    def ws(M, N, K, conv=None, act=0, batch=1, trans=0):
+        p = _lib.GemmParams()
+        p.A, p.W, p.out = 256, 256, 256            # never dereferenced by the query; 16-B aligned
+        p.M, p.N, p.K, p.lda, p.ldw, p.ldo = M, N, K, K, K, N
+        p.alpha, p.act, p.batch, p.trans_out = 1.0, act, batch, trans
+        if conv:                                    # (Nimg, H, Cin): 3x3, stride 1, pad 1, channel-block-major K order
+            p.conv, p.Nimg, p.Hin, p.Win, p.Cin = 2, conv[0], conv[1], conv[1], conv[2]
+            p.Hout = p.Wout = conv[1]
+            p.stride, p.pad = 1, 1
+        return lib.anip_gemm_workspace_bytes(C.byref(p))
+
+    def slices(nbytes, M, N):
+        assert nbytes % (M * N * 4) == 0
+        return nbytes // (M * N * 4)
+
+    # ReferenceNet 8x8 / 16x16 convolutions (two frames): one / four 128-row tiles x 8 column tiles of 160 -> many slices
+    assert 16 <= slices(ws(128, 1280, 11520, conv=(2, 8, 1280)), 128, 1280) <= 32
+    assert 4 <= slices(ws(512, 1280, 23040, conv=(2, 16, 2560)), 512, 1280) <= 32
+    assert 2 <= slices(ws(512, 1280, 5120), 512, 1280) <= 32          # its ff-out Linear
+    # short K, GEGLU, transposed or batched problems and tiny M are never split
+    assert ws(128, 1280, 320) == 0 and ws(512, 1280, 640) == 0
+    assert ws(128, 10240, 1280, act=1) == 0 and ws(128, 1280, 1280, trans=1) == 0 and ws(128, 1280, 5120, batch=2) == 0
+    assert ws(32, 1280, 5120) == 0
+    # the denoising UNet: 8x8 convolutions (M = 2048, K = 11 520) on up to 8 slices of the wide tiles; chip-filling shapes unsplit
+    assert 2 <= slices(ws(2048, 1280, 11520, conv=(32, 8, 1280)), 2048, 1280) <= 8
+    assert ws(8192, 1280, 1280) == 0 and ws(131072, 320, 320) == 0 and ws(32768, 640, 2560) == 0
