@@ -1,17 +1,60 @@
-"""Measurement tooling that must keep up with the kernels (CPU; no GPU, no oracle).
-
-Round 4's last PMC session lost its summary because a kernel added that afternoon (`conv3x3_c4_kernel`) had no family in
-`tools/pmc_summarize.py` and the dispatch <-> wrapper-call pairing stopped at its first launch."""
+"""The measurement tooling's host logic (no GPU): tools/pmc_summarize.py on a synthetic rocprofv3 counter CSV — per-shape
+means, the FETCH_SIZE x2 / calibrated corrections, family aggregation (what bench.py reads for `roofline.traffic`)."""
+import csv
 import importlib.util
+import json
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _write(path, rows):
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    cols = ["Correlation_Id", "Dispatch_Id", "Agent_Id", "Queue_Id", "Process_Id", "Thread_Id", "Grid_Size", "Kernel_Id",
+            "Kernel_Name", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count",
+            "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"]
+    with open(path, "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=cols)
+        w.writeheader()
+        for d, (kern, grid, ctr, val) in enumerate(rows):
+            for xcd in range(2):                      # counters come per XCD / dimension: summed per dispatch
+                w.writerow({c: 0 for c in cols} | {"Dispatch_Id": d, "Correlation_Id": d, "Grid_Size": grid, "Kernel_Name": kern,
+                                                    "Counter_Name": ctr, "Counter_Value": val / 2})
+
+
+def test_pmc_summarize_families_and_calibration(tmp_path):
+    gemm = "_ZN12_GLOBAL__N_112gemm2_kernelILi256ELi160ELi8ELi2ELi32ELi3ELb0ELb0EEEv16anip_gemm_paramsii"
+    conv = "_ZN12_GLOBAL__N_112gemm2_kernelILi256ELi160ELi8ELi2ELi32ELi3ELb1ELb0EEEv16anip_gemm_paramsii"
+    add = "_ZN12_GLOBAL__N_110add_kernelEPKDF16_S1_PDF16_ll"
+    gib_kib = 2**30 / 1024
+    _write(str(tmp_path / "pmc" / "FETCH_SIZE" / "p_counter_collection.csv"),
+           [(add, 1048576, "FETCH_SIZE", gib_kib), (gemm, 524288, "FETCH_SIZE", 1000.0), (gemm, 524288, "FETCH_SIZE", 3000.0),
+            (conv, 524288, "FETCH_SIZE", 500.0)])
+    _write(str(tmp_path / "pmc" / "WRITE_SIZE" / "p_counter_collection.csv"),
+           [(add, 1048576, "WRITE_SIZE", gib_kib), (gemm, 524288, "WRITE_SIZE", 800.0), (gemm, 524288, "WRITE_SIZE", 800.0),
+            (conv, 524288, "WRITE_SIZE", 100.0)])
+    out = tmp_path / "summary.json"
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "pmc_summarize.py"), str(tmp_path / "pmc"), str(out), "--families"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    d = json.load(open(out))
+    # the add kernel read 2 GiB for a reported 1 GiB: factor 2.0; wrote 1 GiB for a reported 1 GiB: factor 1.0
+    assert abs(d["calibration"]["fetch"] - 2.0) < 1e-9 and abs(d["calibration"]["write"] - 1.0) < 1e-9
+    fam = d["families"]
+    g = fam["gemm_kernel<false>"]
+    assert g["launches"] == 2 and abs(g["bytes_per_launch"] - (2000.0 * 1024 * 2 + 800.0 * 1024)) < 1e-6
+    c = fam["gemm_kernel<true> (conv3x3)"]
+    assert c["launches"] == 1 and abs(c["bytes_per_launch"] - (500.0 * 1024 * 2 + 100.0 * 1024)) < 1e-6
+    assert "elementwise" in fam        # the calibration kernel itself
+
+
+# Round 4's last PMC session lost its summary because a kernel added that afternoon (`conv3x3_c4_kernel`) had no family in
+# `tools/pmc_summarize.py` and the dispatch <-> wrapper-call pairing stopped at its first launch.
 def _load(path, name):
     spec = importlib.util.spec_from_file_location(name, path)
     mod = importlib.util.module_from_spec(spec)
@@ -27,11 +70,11 @@ def test_pmc_summarize_knows_every_kernel_of_the_library():
     out = subprocess.run(["nm", "-C", lib], capture_output=True, text=True, check=True).stdout
     kernels = sorted(set(re.findall(r"__device_stub__(\w+)", out)))
     assert len(kernels) > 40, kernels
-    summ = _load(os.path.join(ROOT, "tools", "pmc_summarize.py"), "pmc_summarize")
+    summ = _load(os.path.join(REPO, "tools", "pmc_summarize.py"), "pmc_summarize")
     unknown = [k for k in kernels if summ.family(k) is None]
     assert not unknown, f"tools/pmc_summarize.py: no kernel family for {unknown}"
 
 
 def test_gpu_session_script_parses():
     for script in ("tools/gpu_round4.sh",):
-        subprocess.run(["bash", "-n", os.path.join(ROOT, script)], check=True)
+        subprocess.run(["bash", "-n", os.path.join(REPO, script)], check=True)
