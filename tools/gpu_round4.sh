@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-4 GPU session driver (grown from tools/gpu_round4.sh) (one gpurun call = one invocation): `bash tools/gpu_round4.sh <tag> <step> [<step> ...]`,
+# round-4 GPU session driver (one gpurun call = one invocation; a call costs ~20 s of box time beyond what its steps run): `bash tools/gpu_round4.sh <tag> <step> [<step> ...]`,
 # steps run in the order given:
 #   parity       fixture-based real-width parity tests (C2 4 steps / C5 768 / L=40 windows)
 #   bisect       per-block error table hip vs fp32 oracle at 32x32 / 64x64 latents (tests/bisect_parity.py)
@@ -11,8 +11,11 @@
 #   kbench:<n> / nbench:<n> / ktests:<n> / kcmp:<a>:<b>   micro-benchmarks and kernel tests under the current environment,
 #                A/B table of two kbench runs of this call
 #   valurates / storepattern / ldsdma   instruction issue-rate, store-shape and LDS-DMA micro-benchmarks (tools/exp_*.py)
+#   qbench:<n>   short whole-clip bench (6 clips, no CPU baseline / roofline) under the current environment: whole-clip A/B pairs
+#   mbench:<n>   the small once-per-step / once-per-clip kernels (tools/bench_kernels.py --only=misc)
+#   abench:<n> / atests / pmck:<name>:<what>   attention micro-benchmark / tests, SQ + TCC counter passes over tools/pmc_kernels.py <what>
 #   usepmc       make this call's PMC summary the profiles/pmc_traffic_latest.json that the following bench step reads
-TAG=${1:-r03a}; shift
+TAG=${1:-r04a}; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
