@@ -68,6 +68,34 @@ def test_unets_and_vae_engine_match_reference(emu, gold):
 
 
 @torch.no_grad()
+def test_layernorm_fold_branches_of_the_engine_match_reference(emu, gold, monkeypatch):
+    """ANIP_LN_FOLD=1 (off by default: a measured net loss on MI355X): nn.LayerNorm folded into the q / k / v^T,
+    temporal qkv and GEGLU projections — gamma in the weights, beta W^T in the bias, mean / rstd applied to the accumulators
+    (anip_gemm_params.ln_stats).  The engine's fold branches and hipops.fold_layernorm stay checked against the same goldens."""
+    from aniportrait_amd import engine
+    from golden_inputs import unet_case
+    from src.models.mutual_self_attention import ReferenceAttentionControl
+    monkeypatch.setattr(engine, "_LN_FOLD", True)
+    monkeypatch.setattr(engine, "_ln_ok_cache", {})
+    m, _ = build_hip_models(True, keys=("denoising_unet", "reference_unet"), device="cpu")
+    c = unet_case(True)
+    wr = ReferenceAttentionControl(m["reference_unet"], do_classifier_free_guidance=True, mode="write", batch_size=1,
+                                   fusion_blocks="full")
+    rd = ReferenceAttentionControl(m["denoising_unet"], do_classifier_free_guidance=True, mode="read", batch_size=1,
+                                   fusion_blocks="full")
+    m["reference_unet"](c["ref_lat"].repeat(2, 1, 1, 1), torch.zeros((), dtype=torch.long),
+                        encoder_hidden_states=c["ehs"], return_dict=False)
+    rd.update(wr)
+    for p, rb in m["denoising_unet"]._ref_blocks.items():
+        assert rel_err(rb.node.bank[0].float(), gold["bank/" + p].float()) < TOL, p
+    pose = [gold[f"pose_fea/{i}"] for i in range(5)]
+    out = m["denoising_unet"](c["lat"], torch.tensor(c["t"]), encoder_hidden_states=c["ehs"], pose_cond_fea=pose)
+    assert rel_err(out.sample, gold["unet_out"]) < TOL
+    assert any(v for v in engine._ln_ok_cache.values()), "no GEMM of the walk took the fold: the branch was not exercised"
+    rd.clear(); wr.clear()
+
+
+@torch.no_grad()
 @pytest.mark.parametrize("case", ["long_L4", "long_L10_ctx8"])
 def test_pipeline_host_logic_matches_reference_video(emu, case):
     from aniportrait_amd import configs as C
