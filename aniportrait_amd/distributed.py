@@ -91,10 +91,10 @@ def broadcast_tensors(tensors, src=0, group=None):
 
 def gather_frames(local_frames, local_idx, n_frames, dst=0, group=None, owner_fn=None):
     """local_frames (n_local, ...) holding global frame indices `local_idx`; returns the (n_frames, ...) tensor on
-    `dst` (None elsewhere).  Ranks may own different frame counts: every rank sends EXACTLY its share point-to-point
-    (`batch_isend_irecv` into exact-size staging buffers on `dst`; round 2 padded every rank to the largest share for
-    `dist.gather`) — the frame indices of every rank follow from the sharding rule (`owner_fn(rank) -> indices`,
-    default round robin), so they are not communicated."""
+    `dst` (None elsewhere).  Ranks may own different frame counts.  gloo: every rank sends EXACTLY its share
+    point-to-point (`batch_isend_irecv` into exact-size staging buffers on `dst`); nccl (= RCCL): one `dist.gather` with
+    every share padded to the largest (see the branch).  The frame indices of every rank follow from the sharding rule
+    (`owner_fn(rank) -> indices`, default round robin), so they are not communicated."""
     rank, ws = world(group)
     dev = local_frames.device
     if ws == 1:
