@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # ANIP_LIB: an experiment build of the same ABI (aniportrait_amd/build.py --out=...); the product is the default path
 LIB_PATH = os.environ.get("ANIP_LIB") or os.path.join(HERE, "lib", "libaniportrait_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -58,6 +58,8 @@ SIGNATURES = {
     "anip_row_stats": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "anip_ffn_geglu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                c_void_p]),
+    "anip_ffn_geglu_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_int64, c_int, c_void_p]),
     "anip_conv_small": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                 c_int, c_void_p]),
     "anip_conv_direct": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
@@ -72,6 +74,9 @@ SIGNATURES = {
                                       c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int,
                                       c_float, c_int64, c_int64, c_int, c_void_p]),
     "anip_temporal_attention": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "anip_temporal_qkv_attention_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "anip_temporal_qkv_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                            c_int, c_float, c_float, c_void_p]),
     "anip_softmax_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "anip_linear_small": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "anip_add": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libaniportrait_hip.so")
-SOURCES = ["gemm.hip", "gemm2.hip", "ffn.hip", "norm.hip", "convbn.hip", "attention.hip", "attn_dma.hip", "elementwise.hip", "api.cpp"]
+SOURCES = ["gemm.hip", "gemm2.hip", "ffn.hip", "tblock.hip", "norm.hip", "convbn.hip", "attention.hip", "attn_dma.hip", "elementwise.hip", "api.cpp"]
 ARCH = "gfx950"
 
 

@@ -4,6 +4,8 @@
                         (reference consumer: ``src/models/unet_3d.py:36-83``).
 * ``INFERENCE_V2``   — ``unet_additional_kwargs`` of ``configs/inference/inference_v2.yaml:1-22``.
 * ``DDIM_V2``        — ``noise_scheduler_kwargs`` of ``configs/inference/inference_v2.yaml:24-33``.
+* ``DDIM_V1`` / ``unet3d_kwargs_v1`` — ``configs/inference/inference_v1.yaml``: epsilon prediction, leading spacing, no
+                        zero-SNR rescale; nn.GroupNorm over the sample's frames, no mid-block motion module, 24-frame pe table.
 * ``SD_VAE_FT_MSE``  — sd-vae-ft-mse ``config.json``.
 * ``*_SMALL``        — reduced-width variants with the same topology, used by CPU tests and small
                         parity cases (8 heads kept, head dims 8/16/32 instead of 40/80/160).
@@ -59,6 +61,14 @@ DDIM_V2 = dict(
     timestep_spacing="trailing",
 )
 
+DDIM_V1 = dict(          # configs/inference/inference_v1.yaml:18-23 (everything else at DDIMScheduler's defaults)
+    beta_start=0.00085,
+    beta_end=0.012,
+    beta_schedule="linear",
+    steps_offset=1,
+    clip_sample=False,
+)
+
 SD_VAE_FT_MSE = dict(
     in_channels=3,
     out_channels=3,
@@ -94,6 +104,14 @@ def unet3d_kwargs(small=False):
     """ctor kwargs of ``UNet3DConditionModel`` (SD-1.5 config + inference_v2 additions)."""
     d = copy.deepcopy(SD15_UNET_SMALL if small else SD15_UNET)
     d.update(copy.deepcopy(INFERENCE_V2))
+    return d
+
+
+def unet3d_kwargs_v1(small=False):
+    """ctor kwargs of ``UNet3DConditionModel`` under configs/inference/inference_v1.yaml:1-16"""
+    d = unet3d_kwargs(small)
+    d.update(use_inflated_groupnorm=False, motion_module_mid_block=False)
+    d["motion_module_kwargs"]["temporal_position_encoding_max_len"] = 24
     return d
 
 

@@ -4,6 +4,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "../../include/aniportrait_hip.h"
@@ -40,6 +43,39 @@ extern "C" int anip_device_info(char* arch, int arch_len, int* num_cu) {
   }
   if (num_cu) *num_cu = prop.multiProcessorCount;
   return 0;
+}
+
+// ---- per-device caches (any device ordinal: a CPX-partitioned node exposes up to 64) ------------------------------------------
+namespace {
+std::mutex g_dev_mu;
+std::map<std::pair<const void*, int>, int> g_lds_limit;   // (kernel, device) -> dynamic LDS limit already granted
+std::map<int, int> g_cu_count;
+}  // namespace
+
+int anip_raise_lds_limit(const void* kernel, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  int& have = g_lds_limit[std::make_pair(kernel, dev)];
+  if (have >= bytes) return 0;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  have = bytes;
+  return 0;
+}
+
+int anip_cu_count() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  auto it = g_cu_count.find(dev);
+  if (it != g_cu_count.end()) return it->second;
+  hipDeviceProp_t prop;
+  const int n = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : -1;
+  g_cu_count[dev] = n;
+  return n;
 }
 
 // ---- per-kernel HIP-event profiling -------------------------------------------------------------

@@ -465,15 +465,9 @@ namespace {
 template <int D, int NW>
 int launch_dma(const RefAttnArgs& a, int Nf, hipStream_t stream) {
   using G = Geo<D>;
-  static bool attr_done[16] = {};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev >= 0 && dev < 16 && !attr_done[dev]) {
-    if (hipFuncSetAttribute((const void*)ref_attn_dma_kernel<D, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess) {
-      anip_set_error("anip_ref_attention: cannot raise the dynamic LDS limit to %d bytes", G::LDS);
-      return -2;
-    }
-    attr_done[dev] = true;
+  if (anip_raise_lds_limit((const void*)ref_attn_dma_kernel<D, NW>, G::LDS) != 0) {
+    anip_set_error("anip_ref_attention: cannot raise the dynamic LDS limit to %d bytes", G::LDS);
+    return -2;
   }
   dim3 grid((unsigned)(a.T / (32 * NW)), (unsigned)a.heads, (unsigned)Nf);
   AnipProfScope prof_(ANIP_K_REF_ATTN, (void*)stream);

@@ -16,6 +16,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 void anip_set_error(const char* fmt, ...);
+// hipFuncAttributeMaxDynamicSharedMemorySize >= bytes for `kernel` on the CURRENT device, cached per (kernel, device ordinal)
+// for any ordinal (api.cpp); 0 on success
+int anip_raise_lds_limit(const void* kernel, int bytes);
+// CU count of the current device, cached per ordinal (-1 if the query fails)
+int anip_cu_count();
 
 #define ANIP_REQUIRE(cond, ...)        \
   do {                                 \

@@ -57,9 +57,12 @@ struct FfnArgs {
   const f16* res;    // [M][C] or null
   f16* out;          // [M][C]
   int M;
+  const float* gamma;  // LN variant: x holds the RAW rows, LayerNorm(gamma, beta, eps) is applied while the x tile is staged
+  const float* beta;
+  float eps;
 };
 
-template <int C_>
+template <int C_, bool LN>
 __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs a) {
   constexpr int BM = 128;
   constexpr int KT = C_ / 64;            // 64-deep K-tiles of x / W1
@@ -132,9 +135,56 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs a) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  if constexpr (LN) {
+    // LayerNorm in the prologue (round 5): four lanes per row (16-B chunks part, part + 4, ..), statistics from registers, the
+    // normalised row written as fp16 into the same swizzled planes the LDS-DMA path fills — the stand-alone layernorm launch
+    // (84 MB read + 84 MB written per 64x64 layer) and the second input tensor are gone.  W1's first tile streams meanwhile.
+    issue_w1(0, 0, 0);
+    constexpr int NCH = C_ / 8 / 4;            // chunks per lane
+    const int row = tid >> 2, part = tid & 3;
+    const int m = m0 + row;
+    const f16* xr = a.x + (int64_t)(m < a.M ? m : 0) * C_;
+    U4H8 v[NCH];
 #pragma unroll
-  for (int kt = 0; kt < KT; ++kt) issue_x(kt);
-  issue_w1(0, 0, 0);
+    for (int i = 0; i < NCH; ++i) v[i].u = *(const u32x4*)(xr + (part + 4 * i) * 8);
+    float sm = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sm += (float)v[i].e[e];
+    sm += __shfl_xor(sm, 1, 64);
+    sm += __shfl_xor(sm, 2, 64);
+    const float mean = sm / (float)C_;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = (float)v[i].e[e] - mean;
+        q += d * d;
+      }
+    q += __shfl_xor(q, 1, 64);
+    q += __shfl_xor(q, 2, 64);
+    const float rstd = rsqrtf(q / (float)C_ + a.eps);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+      const int c = part + 4 * i;              // 16-B chunk of the row: plane c / 8, slot (c % 8) ^ (row & 7)
+      const float4 g0 = *(const float4*)(a.gamma + c * 8), g1 = *(const float4*)(a.gamma + c * 8 + 4);
+      const float4 b0 = *(const float4*)(a.beta + c * 8), b1 = *(const float4*)(a.beta + c * 8 + 4);
+      const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      U4H8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o.e[e] = (f16)(((float)v[i].e[e] - mean) * rstd * gg[e] + bb[e]);
+      if (m >= a.M) o.u = u32x4{0u, 0u, 0u, 0u};
+      *(u32x4*)(smem + (c >> 3) * PLANE + row * 128 + (((c & 7) ^ (row & 7)) << 4)) = o.u;
+    }
+    __syncthreads();
+  } else {
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) issue_x(kt);
+    issue_w1(0, 0, 0);
+  }
 
   for (int c = 0; c < NCHUNK; ++c) {
     const int base = c & 1;                                    // K-tile kt of this chunk lives in stage (kt + base) & 1
@@ -329,22 +379,42 @@ extern "C" int anip_ffn_geglu(const void* x, const void* w1p, const float* b1p, 
   FfnArgs a;
   a.x = (const f16*)x; a.w1p = (const f16*)w1p; a.b1p = b1p; a.w2 = (const f16*)w2; a.b2 = b2;
   a.res = (const f16*)residual; a.out = (f16*)out; a.M = (int)M;
+  a.gamma = nullptr; a.beta = nullptr; a.eps = 0.f;
   constexpr int LDS = (320 / 64 + 2) * 128 * 128 + 320 * 128;
-  static bool attr_done_dev[16] = {};    // the attribute is per device
-  int dev_ = 0;
-  if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ > 15) dev_ = 15;
-  bool& attr_done = attr_done_dev[dev_];
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)ffn_geglu_kernel<320>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-      anip_set_error("anip_ffn_geglu: cannot raise the dynamic LDS limit to %d bytes", LDS);
-      return -2;
-    }
-    attr_done = true;
+  if (anip_raise_lds_limit((const void*)ffn_geglu_kernel<320, false>, LDS) != 0) {
+    anip_set_error("anip_ffn_geglu: cannot raise the dynamic LDS limit to %d bytes", LDS);
+    return -2;
   }
   {
     AnipProfScope prof_(ANIP_K_GEMM, stream);
-    hipLaunchKernelGGL(ffn_geglu_kernel<320>, dim3((unsigned)((M + 127) / 128)), dim3(512), LDS, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((ffn_geglu_kernel<320, false>), dim3((unsigned)((M + 127) / 128)), dim3(512), LDS, (hipStream_t)stream, a);
   }
   ANIP_LAUNCH_CHECK("anip_ffn_geglu");
+  return 0;
+}
+
+// out = residual + FeedForward(LayerNorm(x; gamma, beta, eps)) — the LayerNorm applied while the x tile is staged
+extern "C" int anip_ffn_geglu_ln(const void* x, const float* gamma, const float* beta, float eps, const void* w1p,
+                                 const float* b1p, const void* w2, const float* b2, const void* residual, void* out,
+                                 int64_t M, int C, void* stream) {
+  ANIP_REQUIRE(x && gamma && beta && w1p && b1p && w2 && out, "anip_ffn_geglu_ln: null pointer");
+  ANIP_REQUIRE(C == 320, "anip_ffn_geglu_ln: only C = 320 is built (got %d); use anip_layernorm + two anip_gemm calls", C);
+  ANIP_REQUIRE(M > 0 && M * (int64_t)C * 2 < 0xFFFFF000ll, "anip_ffn_geglu_ln: bad M=%lld", (long long)M);
+  ANIP_REQUIRE((((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)w1p | (uintptr_t)w2 | (uintptr_t)out |
+                 (uintptr_t)residual | (uintptr_t)b2) & 15) == 0, "anip_ffn_geglu_ln: pointers must be 16-B aligned");
+  FfnArgs a;
+  a.x = (const f16*)x; a.w1p = (const f16*)w1p; a.b1p = b1p; a.w2 = (const f16*)w2; a.b2 = b2;
+  a.res = (const f16*)residual; a.out = (f16*)out; a.M = (int)M;
+  a.gamma = gamma; a.beta = beta; a.eps = eps;
+  constexpr int LDS = (320 / 64 + 2) * 128 * 128 + 320 * 128;
+  if (anip_raise_lds_limit((const void*)ffn_geglu_kernel<320, true>, LDS) != 0) {
+    anip_set_error("anip_ffn_geglu_ln: cannot raise the dynamic LDS limit to %d bytes", LDS);
+    return -2;
+  }
+  {
+    AnipProfScope prof_(ANIP_K_GEMM, stream);
+    hipLaunchKernelGGL((ffn_geglu_kernel<320, true>), dim3((unsigned)((M + 127) / 128)), dim3(512), LDS, (hipStream_t)stream, a);
+  }
+  ANIP_LAUNCH_CHECK("anip_ffn_geglu_ln");
   return 0;
 }

@@ -1139,20 +1139,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
 #undef ANIP_G2_MMA
 }
 
-inline int gemm2_device() {             // ordinal of the current device, clamped into the per-device caches below
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
-  return dev < 16 ? dev : 15;
-}
-inline int gemm2_cu_count() {           // per device: partitions of one node may expose different CU counts
-  static int n[16] = {};
-  const int dev = gemm2_device();
-  if (n[dev] == 0) {
-    hipDeviceProp_t prop;
-    n[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : -1;
-  }
-  return n[dev];
-}
+inline int gemm2_cu_count() { return anip_cu_count(); }   // per device ordinal (api.cpp): partitions of one node may differ
 
 static thread_local bool g_gemm2_dry_run = false;   // anip_gemm2_would_take: walk the dispatch, launch nothing
 
@@ -1161,15 +1148,12 @@ int launch_gemm2(const anip_gemm_params& p, hipStream_t stream, int splitk = 1) 
   constexpr int NT2 = NW * 64;
   if (g_gemm2_dry_run) return 1;
   constexpr int LDS = NST * (BM2 + BN) * BKT * 2;
-  static bool attr_done_dev[16] = {};   // the attribute is per device
-  bool& attr_done = attr_done_dev[gemm2_device()];
-  if (!attr_done) {
+  {
     auto kfn = gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS, LNF>;
-    if (hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+    if (anip_raise_lds_limit((const void*)kfn, LDS) != 0) {
       anip_set_error("anip_gemm: cannot raise the dynamic LDS limit to %d bytes", LDS);
       return -2;
     }
-    attr_done = true;
   }
   const int nbm = (p.M + BM2 - 1) / BM2, nbn = (p.N + BN - 1) / BN;
   unsigned grid = (unsigned)(nbm * nbn);

@@ -149,6 +149,23 @@ class PackedNet:
             self.t[k] = self._raw(name).to(self.device, F32).reshape(-1, C).contiguous()
         return self.t[k]
 
+    def beta_pe(self, norm, pe_name, C, f):
+        """fp32 [f][C]: the LayerNorm's bias plus the frame's positional encoding (bias alone when the attention has no encoder)"""
+        k = ("betape", norm, pe_name, int(f))
+        if k not in self.t:
+            t = self.f32(norm + ".bias")[None, :].repeat(f, 1)
+            if pe_name is not None:
+                t = t + self.pe(pe_name, C)[:f]
+            self.t[k] = t.contiguous()
+        return self.t[k]
+
+    def tqkv(self, names):
+        """[to_q; to_k; to_v] in anip_temporal_qkv_attention's head-pair row order"""
+        k = ("tqkv",) + tuple(names)
+        if k not in self.t:
+            self.t[k] = ops.pack_temporal_qkv(*[self._raw(n).to(self.device, F16) for n in names])
+        return self.t[k]
+
     def temb_stack(self, names):
         """all time_emb_proj layers stacked: W fp16 [sum Cout][temb], bias fp32, and column offsets."""
         k = ("tembstack",)
@@ -211,6 +228,9 @@ def resnet(net, p, x, skip, temb_rb, rows_per_group, eps, groups=32, gn_frames=1
 # round 2 (every step inside the captured graph), 1-4 % faster end to end (10.39 / 10.41 vs 9.99 / 10.31 frames/s in two
 # paired runs).  ANIP_FUSED_FFN=0 selects the two-GEMM path.
 _FUSED_FFN = os.environ.get("ANIP_FUSED_FFN", "1") == "1"
+# the block's LayerNorm (norm3 / ff_norm) inside the fused kernel's prologue (round 5): no layernorm launch, one input tensor
+# instead of two.  ANIP_FFN_LN=0 selects layernorm + anip_ffn_geglu (A/B measurements).
+_FFN_LN = os.environ.get("ANIP_FFN_LN", "1") == "1"
 
 
 # nn.LayerNorm folded into the GEMM it feeds (anip_gemm_params.ln_stats): the consumer reads the raw rows, gamma sits in its
@@ -221,6 +241,10 @@ _FUSED_FFN = os.environ.get("ANIP_FUSED_FFN", "1") == "1"
 # — their K = 320 .. 1280 main loops are short, and the extra dependent loads of the accumulator transform sit exposed in front
 # of the stores.  ANIP_LN_FOLD=1 selects it (A/B measurements, tests).
 _LN_FOLD = os.environ.get("ANIP_LN_FOLD", "0") == "1"
+
+# LayerNorm(+pe) -> to_q / to_k / to_v -> temporal attention as ONE launch at C = 320, F = 16 (csrc/tblock.hip): the normalised
+# rows and the M x 960 q|k|v matrix never reach HBM.  ANIP_FUSED_TEMPORAL=0 selects the three-launch path (A/B measurements).
+_FUSED_TEMPORAL = os.environ.get("ANIP_FUSED_TEMPORAL", "1") == "1"
 _ln_ok_cache = {}
 
 
@@ -240,8 +264,11 @@ def feed_forward(net, p, h, norm):
         wp, cs, bp = net.ln_lin((p + ".net.0.proj.weight",), p + ".net.0.proj.bias", norm, geglu=True)
         g = ops.gemm(h, wp, bp, act=1, ln=(ops.row_stats(h), cs))
         return ops.gemm(g, net.lin(p + ".net.2.weight"), net.f32(p + ".net.2.bias"), residual=h)
-    n_in = ops.layernorm(h, net.f32(norm + ".weight"), net.f32(norm + ".bias"))
     wp, bp = net.geglu(p + ".net.0.proj")
+    if fused and _FFN_LN:
+        return ops.ffn_geglu_ln(h, net.f32(norm + ".weight"), net.f32(norm + ".bias"), wp, bp, net.lin(p + ".net.2.weight"),
+                                net.f32(p + ".net.2.bias"), h)
+    n_in = ops.layernorm(h, net.f32(norm + ".weight"), net.f32(norm + ".bias"))
     if fused:
         return ops.ffn_geglu(n_in, wp, bp, net.lin(p + ".net.2.weight"), net.f32(p + ".net.2.bias"), h)
     g = ops.gemm(n_in, wp, bp, act=1)
@@ -383,6 +410,13 @@ def motion_module(net, p, x, b, f, heads):
         # LN + positional encoding of the frame (added to the attention INPUT: q, k and v see it; the
         # residual below uses the un-encoded h — src/models/motion_module.py:244-254,365-366)
         wn = (ap + ".to_q.weight", ap + ".to_k.weight", ap + ".to_v.weight")
+        if _FUSED_TEMPORAL and ops.temporal_qkv_attention_supported(f, T, C, heads):
+            a = ops.temporal_qkv_attention(h, net.f32(bp + f".norms.{i}.weight"),
+                                           net.beta_pe(bp + f".norms.{i}", pe_name if pe is not None else None, C, f),
+                                           net.tqkv(wn), b, f, T, heads)
+            h = ops.gemm(a, net.lin(ap + ".to_out.0.weight"), net.f32(ap + ".to_out.0.bias"), residual=h)
+            i += 1
+            continue
         if _ln_ok(N * T, 3 * C, C):
             # folded: (LN(h) + pe_f) W^T = rstd (h W'^T - mean s) + beta W^T + pe_f W^T, the last term a per-frame row bias
             Wf, cs, bf = net.ln_lin(wn, None, bp + f".norms.{i}")

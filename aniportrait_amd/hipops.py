@@ -447,6 +447,24 @@ def ffn_geglu(x, w1p, b1p, w2, b2, residual=None):
     return out
 
 
+def ffn_geglu_ln(x, gamma, beta, w1p, b1p, w2, b2, residual=None, eps=1e-5):
+    """residual + FeedForward(LayerNorm(x)) in one launch (anip_ffn_geglu_ln; C = 320): x (M, C) fp16 RAW rows, gamma / beta (C,)
+    fp32, the rest as ffn_geglu"""
+    lib = L.load()
+    _req(x, F16, "x")
+    _req(w1p, F16, "w1p")
+    _req(w2, F16, "w2")
+    M, Cc = x.shape
+    assert tuple(w1p.shape) == (8 * Cc, Cc) and tuple(w2.shape) == (Cc, 4 * Cc)
+    out = torch.empty_like(x)
+    _work(K_GEMM, 2 * M * Cc * (8 * Cc) + 2 * M * Cc * (4 * Cc), f"ffn_geglu_ln M{M} C{Cc}",
+          M * Cc * 2 * 2 + 12 * Cc * Cc * 2)
+    L.check(lib.anip_ffn_geglu_ln(_p(x), _p(_req(gamma, F32, "gamma")), _p(_req(beta, F32, "beta")), float(eps), _p(w1p),
+                                  _p(_req(b1p, F32, "b1p")), _p(w2), _p(b2), _p(residual), _p(out), M, Cc, _stream()),
+            "anip_ffn_geglu_ln")
+    return out
+
+
 def conv3x3(x, Wp, bias, stride=1, pad=1, upsample=False, pad_hi=None, rowbias=None, rows_per_group=0,
             residual=None, out_f32=False, korder=None, debug_ws=None):
     """x (N, H, W, Cin) fp16, Wp (Cout, 9*Cin) packed by pack_conv3x3 -> (N, Ho, Wo, Cout).
@@ -557,6 +575,41 @@ def temporal_attention(qkv, B, F, T, heads, d, scale=None):
     _work(K_TEMPORAL_ATTN, B * F * T * heads * d * 4 * 2, f"B{B} F{F} T{T} h{heads} d{d}")
     L.check(lib.anip_temporal_attention(_p(qkv), _p(out), B, F, T, heads, d, float(scale), _stream()),
             "anip_temporal_attention")
+    return out
+
+
+def pack_temporal_qkv(wq, wk, wv):
+    """[to_q; to_k; to_v] of a C = 320 motion-module attention (each (320, 320) fp16) in the row order of
+    anip_temporal_qkv_attention: per head PAIR p its 80 to_q rows, 80 to_k rows, 80 to_v rows"""
+    assert tuple(wq.shape) == tuple(wk.shape) == tuple(wv.shape) == (320, 320)
+    parts = []
+    for p_ in range(4):
+        for w in (wq, wk, wv):
+            parts.append(w[80 * p_:80 * p_ + 80])
+    return torch.cat(parts, dim=0).to(F16).contiguous()
+
+
+def temporal_qkv_attention_supported(F, T, C, heads):
+    return bool(L.load().anip_temporal_qkv_attention_supported(int(F), int(T), int(C), int(heads)))
+
+
+def temporal_qkv_attention(x, gamma, beta_pe, w_packed, B, F, T, heads, eps=1e-5, scale=None):
+    """LayerNorm(+pe) -> to_q / to_k / to_v -> temporal self-attention in one launch (anip_temporal_qkv_attention; F = 16,
+    C = 320, 8 heads): x (B*F*T, C) fp16, gamma (C,) fp32, beta_pe (F, C) fp32 = norm bias + pe[frame], w_packed from
+    pack_temporal_qkv -> attention output (B*F*T, C) fp16 (the input of to_out)."""
+    lib = L.load()
+    _req(x, F16, "x")
+    _req(w_packed, F16, "w_packed")
+    M, Cc = x.shape
+    d = Cc // heads
+    assert M == B * F * T and tuple(w_packed.shape) == (3 * Cc, Cc) and tuple(beta_pe.shape) == (F, Cc)
+    if scale is None:
+        scale = d ** -0.5
+    out = torch.empty_like(x)
+    _work(K_GEMM, 2 * M * 3 * Cc * Cc + 4 * M * F * Cc, f"tqkv_attn M{M} C{Cc} F{F}", M * Cc * 2 * 2 + 3 * Cc * Cc * 2)
+    L.check(lib.anip_temporal_qkv_attention(_p(x), _p(_req(gamma, F32, "gamma")), _p(_req(beta_pe, F32, "beta_pe")),
+                                            _p(w_packed), _p(out), B, F, T, Cc, heads, float(eps), float(scale), _stream()),
+            "anip_temporal_qkv_attention")
     return out
 
 

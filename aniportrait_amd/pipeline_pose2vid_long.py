@@ -357,15 +357,17 @@ class Pose2VideoPipeline(_Base):
         sch = self.scheduler
         if hasattr(sch, "coefficients"):
             return sch.coefficients(t)
-        # a foreign (diffusers) DDIMScheduler with the same configuration
+        # a foreign (diffusers) DDIMScheduler: the same arithmetic from its tables
+        from .scheduling_ddim import linear_step_form
         cfg = sch.config
-        if type(sch).__name__ != "DDIMScheduler" or cfg.prediction_type != "v_prediction" or cfg.clip_sample:
-            raise NotImplementedError("the fused CFG+DDIM kernel implements DDIMScheduler / v_prediction / "
-                                      "clip_sample=False (configs/inference/inference_v2.yaml:24-33)")
+        if type(sch).__name__ != "DDIMScheduler" or cfg.clip_sample:
+            raise NotImplementedError("the fused CFG+DDIM kernel implements DDIMScheduler with clip_sample=False "
+                                      "(configs/inference/inference_v1.yaml:18-23, inference_v2.yaml:24-33)")
         prev = int(t) - cfg.num_train_timesteps // sch.num_inference_steps
         a_t = float(sch.alphas_cumprod[int(t)])
         a_p = float(sch.alphas_cumprod[prev]) if prev >= 0 else float(sch.final_alpha_cumprod)
-        return math.sqrt(a_t), math.sqrt(max(1 - a_t, 0.0)), math.sqrt(a_p), math.sqrt(max(1 - a_p, 0.0))
+        return linear_step_form(cfg.prediction_type, math.sqrt(a_t), math.sqrt(max(1 - a_t, 0.0)), math.sqrt(a_p),
+                                math.sqrt(max(1 - a_p, 0.0)))
 
     max_cached_graphs = 4   # window shapes whose captured graph (+ private pool, static buffers) stay resident
 

@@ -29,6 +29,21 @@ def _zero_terminal_snr(betas):
     return 1.0 - alphas
 
 
+def linear_step_form(prediction_type, sa, sb, sap, sbp):
+    """(sa, sb, sap, sbp) as anip_cfg_ddim_step takes them, for any prediction type — see DDIMScheduler.coefficients"""
+    if prediction_type == "v_prediction":
+        return sa, sb, sap, sbp
+    if prediction_type == "epsilon":
+        if sa <= 0.0:
+            raise ValueError("epsilon prediction at alpha_bar = 0 (zero terminal SNR needs v-prediction)")
+        return 1.0, 0.0, sap / sa, sbp - sap * sb / sa
+    if prediction_type == "sample":
+        if sb <= 0.0:
+            raise ValueError("sample prediction at alpha_bar = 1")
+        return 1.0, 0.0, sbp / sb, sap - sbp * sa / sb
+    raise ValueError(f"prediction_type {prediction_type}")
+
+
 class DDIMScheduler:
     order = 1
     _defaults = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
@@ -93,13 +108,19 @@ class DDIMScheduler:
         return a_t, a_p
 
     def coefficients(self, t):
-        """(sqrt(abar_t), sqrt(1-abar_t), sqrt(abar_prev), sqrt(1-abar_prev)) of the eta=0 v-prediction step:
-        x0 = sa x - sb v ; eps = sa v + sb x ; x_prev = sap x0 + sbp eps."""
-        if self.config.prediction_type != "v_prediction" or self.config.clip_sample:
-            raise NotImplementedError("fused step: only prediction_type='v_prediction', clip_sample=False "
-                                      "(configs/inference/inference_v2.yaml:24-33)")
+        """Four scalars (sa, sb, sap, sbp) of one deterministic (eta = 0, unclipped) step in the form the fused CFG + DDIM kernel
+        evaluates:  x0 = sa x - sb m ; eps = sa m + sb x ; x_prev = sap x0 + sbp eps   (m = the guided model output).
+        v-prediction (configs/inference/inference_v2.yaml:24-33): the four square roots themselves.  Epsilon / sample prediction
+        (configs/inference/inference_v1.yaml:18-23 is epsilon, leading spacing, no zero-SNR): every such step is linear,
+        x_prev = cx x + cm m, passed as (1, 0, cx, cm):
+            epsilon:  x0 = (x - sb m) / sa          ->  cx = sap / sa,  cm = sbp - sap sb / sa
+            sample:   eps = (x - sa m) / sb         ->  cx = sbp / sb,  cm = sap - sbp sa / sb"""
+        if self.config.clip_sample:
+            raise NotImplementedError("fused step: clip_sample=False only (both shipped inference configs; clipping x0 is not "
+                                      "a linear step)")
         a_t, a_p = self._abar(t)
-        return math.sqrt(a_t), math.sqrt(max(1.0 - a_t, 0.0)), math.sqrt(a_p), math.sqrt(max(1.0 - a_p, 0.0))
+        sa, sb, sap, sbp = math.sqrt(a_t), math.sqrt(max(1.0 - a_t, 0.0)), math.sqrt(a_p), math.sqrt(max(1.0 - a_p, 0.0))
+        return linear_step_form(self.config.prediction_type, sa, sb, sap, sbp)
 
     def step(self, model_output, timestep, sample, eta=0.0, use_clipped_model_output=False, generator=None,
              variance_noise=None, return_dict=True):

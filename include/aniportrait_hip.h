@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ANIP_ABI_VERSION 13
+#define ANIP_ABI_VERSION 14
 
 int anip_version(void);
 const char* anip_last_error(void);
@@ -128,6 +128,11 @@ int anip_row_stats(const void* x, int64_t ld, float* stats, int64_t M, int C, fl
  * fp16 or NULL.  Only C = 320 is built. */
 int anip_ffn_geglu(const void* x, const void* w1p, const float* b1p, const void* w2, const float* b2,
                    const void* residual, void* out, int64_t M, int C, void* stream);
+/* same with the block's LayerNorm inside: out = residual + FeedForward(LayerNorm(x; gamma, beta, eps)) — norm3 / ff_norm of
+ * src/models/attention.py:436-445 / src/models/motion_module.py:256-257 applied while the x tile is staged (x holds the RAW
+ * rows; the engine passes residual = x).  gamma, beta [C] fp32.  Only C = 320 is built. */
+int anip_ffn_geglu_ln(const void* x, const float* gamma, const float* beta, float eps, const void* w1p, const float* b1p,
+                      const void* w2, const float* b2, const void* residual, void* out, int64_t M, int C, void* stream);
 
 /* ---- small-channel direct convolution (Cin or Cout not MFMA-shaped) -----------------------------
  * conv_in 4->C (src/models/unet_3d.py:90-92,484), AutoencoderKL post_quant_conv / decoder.conv_in.
@@ -186,6 +191,21 @@ int anip_ref_attention_ex(const void* q, int64_t ldq, const void* k, int64_t ldk
  * attention over the F frames.  qkv [(b F) T][3C] fp16 (q|k|v), out [(b F) T][C]. */
 int anip_temporal_attention(const void* qkv, void* out, int B, int F, int T, int heads, int d, float scale,
                             void* stream);
+
+/* ---- fused front half of a motion-module attention block ---------------------------------------------
+ * replaces norms[i] -> PositionalEncoding -> to_q / to_k / to_v -> VersatileAttention's softmax(q k^T / sqrt d) v
+ * (src/models/motion_module.py:236-259 TemporalTransformerBlock.forward, :283-296, :351-388) in one launch; the block's
+ * to_out + residual stays an anip_gemm call.
+ *   x        [(b F) T][C] fp16   hidden states h of the block
+ *   gamma    [C] fp32            norms[i].weight
+ *   beta_pe  [F][C] fp32         norms[i].bias + pos_encoder.pe[frame]   (bias alone, repeated, when there is no encoder)
+ *   w_packed [3C][C] fp16        per head PAIR p = 0..3: rows 240 p + {0..79: to_q rows 80 p.., 80..159: to_k, 160..239: to_v}
+ *   out      [(b F) T][C] fp16   attention output (token-major, heads concatenated) = input of to_out
+ * Built for F = 16, C = 320, heads = 8 (d = 40), T % 8 == 0 — anip_temporal_qkv_attention_supported tells (1 / 0);
+ * every other shape stays on anip_layernorm + anip_gemm + anip_temporal_attention.  scale = d^-1/2 of the reference. */
+int anip_temporal_qkv_attention_supported(int F, int T, int C, int heads);
+int anip_temporal_qkv_attention(const void* x, const float* gamma, const float* beta_pe, const void* w_packed, void* out,
+                                int B, int F, int T, int C, int heads, float eps, float scale, void* stream);
 
 /* ---- row softmax fp32 -> fp16 (VAE mid-block attention, diffusers Attention upcast_softmax) ---- */
 int anip_softmax_rows(const float* s, void* p, int64_t rows, int cols, void* stream);

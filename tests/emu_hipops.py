@@ -113,6 +113,10 @@ def ffn_geglu(x, w1p, b1p, w2, b2, residual=None):
     return y.to(F16)
 
 
+def ffn_geglu_ln(x, gamma, beta, w1p, b1p, w2, b2, residual=None, eps=1e-5):
+    return ffn_geglu(layernorm(x, gamma, beta, eps), w1p, b1p, w2, b2, residual)
+
+
 def conv3x3(x, Wp, bias, stride=1, pad=1, upsample=False, pad_hi=None, rowbias=None, rows_per_group=0,
             residual=None, out_f32=False, korder=None):
     N, H, Wd, Cin = x.shape
@@ -199,6 +203,23 @@ def temporal_attention(qkv, B, Fr, T, heads, d, scale=None):
     return o.reshape(B * Fr * T, C).to(F16).contiguous()
 
 
+def temporal_qkv_attention_supported(Fr, T, C, heads):
+    return Fr == 16 and C == 320 and heads == 8 and T > 0 and T % 8 == 0
+
+
+def temporal_qkv_attention(x, gamma, beta_pe, w_packed, B, Fr, T, heads, eps=1e-5, scale=None):
+    """LayerNorm + (beta + pe[frame]) -> packed [q | k | v per head pair] projection -> temporal attention, with the fp16
+    roundings the kernel has (normalised rows, q / k / v)"""
+    M, C = x.shape
+    d = C // heads
+    nh = F.layer_norm(x.float(), (C,), gamma.float(), None, eps)
+    idx = (torch.arange(M) // T) % Fr
+    nh = (nh + beta_pe.float()[idx]).to(F16)
+    y = (nh.float() @ w_packed.float().t()).to(F16).reshape(M, 4, 3, 80)          # (row, head pair, q|k|v, 80)
+    qkv = y.permute(0, 2, 1, 3).reshape(M, 3 * C).contiguous()                     # q | k | v, heads in order
+    return temporal_attention(qkv, B, Fr, T, heads, d, scale)
+
+
 def softmax_rows(s):
     return torch.softmax(s.float(), dim=-1).to(F16)
 
@@ -262,8 +283,8 @@ def f16_to_u8(src, scale=1.0, shift=0.0):
     return ((src.float() * scale + shift).clamp(0, 1).to(F16).float() * 255.0).to(torch.uint8)
 
 
-_EMULATED = ("groupnorm", "layernorm", "gemm", "row_stats", "gemm_supports_ln", "ffn_geglu", "conv3x3", "conv_small", "conv_direct", "batchnorm", "ref_attention",
-             "temporal_attention", "softmax_rows", "linear_small", "add", "window_accumulate", "cfg_ddim_step",
+_EMULATED = ("groupnorm", "layernorm", "gemm", "row_stats", "gemm_supports_ln", "ffn_geglu", "ffn_geglu_ln", "conv3x3", "conv_small", "conv_direct", "batchnorm", "ref_attention",
+             "temporal_attention", "temporal_qkv_attention", "temporal_qkv_attention_supported", "softmax_rows", "linear_small", "add", "window_accumulate", "cfg_ddim_step",
              "ncfhw_to_nhwc", "nhwc_to_ncfhw", "u8_to_f16", "f16_to_u8")
 
 

@@ -58,6 +58,9 @@ REAL_PIPE_CASES = {
     "l40_windows": (128, 128, 40, 3, 3.5, 4, (0, 11, 12, 23, 36, 39)),  # 4 windows / step incl. the wrap-around one
     "c2_25step": (512, 512, 16, 25, 3.5, 2, tuple(range(16))),    # BASELINE configs[1] IN FULL: the schedule bench.py times
     "c5_4step": (768, 768, 16, 4, 3.5, 3, (0, 5, 10, 15)),        # BASELINE configs[4] geometry, 4 of 25 DDIM steps
+    # BASELINE configs[3] at its OWN geometry: 512x512, L=150 -> 13 overlapping 16-frame windows per step (the last one
+    # wrapping around the clip end), 1 DDIM step; stored frames sit in plain, overlapping and wrap-around windows
+    "c4_1step": (512, 512, 150, 1, 3.5, 5, (0, 5, 12, 75, 146, 149)),
 }
 
 

@@ -146,3 +146,57 @@ def test_inference_v1_groupnorm_variant_engine_matches_reference(emu):
     gold = load_golden("small_models_v1.pt")
     assert rel_err(out.sample, gold["unet_out_v1"]) < TOL
     assert rel_err(out.sample, gold["unet_out_v1_if_inflated"]) > 1e-2
+
+
+@torch.no_grad()
+def test_fused_temporal_branch_of_the_motion_module_matches_the_three_launch_branch(emu, monkeypatch):
+    """C = 320, F = 16 (the 64x64 level): engine.motion_module through anip_temporal_qkv_attention's packing (head-pair row order
+    of [to_q; to_k; to_v], bias + positional-encoding table) against the LayerNorm -> GEMM -> temporal attention branch and
+    against plain fp32 arithmetic of src/models/motion_module.py:236-259,351-388"""
+    import torch.nn.functional as Fn
+
+    from aniportrait_amd import engine
+    g = torch.Generator().manual_seed(5)
+    C, heads, f, b, H, W = 320, 8, 16, 1, 2, 4
+    r = lambda *s, scale=1.0: (torch.randn(s, generator=g) * scale).half().float()
+    p = "mm.temporal_transformer"
+    bp = p + ".transformer_blocks.0"
+    sd = {p + ".norm.weight": 1 + 0.1 * r(C), p + ".norm.bias": 0.1 * r(C),
+          p + ".proj_in.weight": r(C, C, scale=C ** -0.5), p + ".proj_in.bias": 0.1 * r(C),
+          p + ".proj_out.weight": r(C, C, scale=C ** -0.5), p + ".proj_out.bias": 0.1 * r(C),
+          bp + ".ff_norm.weight": 1 + 0.1 * r(C), bp + ".ff_norm.bias": 0.1 * r(C),
+          bp + ".ff.net.0.proj.weight": r(8 * C, C, scale=C ** -0.5), bp + ".ff.net.0.proj.bias": 0.1 * r(8 * C),
+          bp + ".ff.net.2.weight": r(C, 4 * C, scale=(4 * C) ** -0.5), bp + ".ff.net.2.bias": 0.1 * r(C)}
+    for i in range(2):
+        ap = bp + f".attention_blocks.{i}"
+        for n in ("to_q", "to_k", "to_v"):
+            sd[ap + f".{n}.weight"] = r(C, C, scale=C ** -0.5)
+        sd[ap + ".to_out.0.weight"] = r(C, C, scale=C ** -0.5)
+        sd[ap + ".to_out.0.bias"] = 0.1 * r(C)
+        sd[ap + ".pos_encoder.pe"] = 0.5 * r(1, 24, C)
+        sd[bp + f".norms.{i}.weight"] = 1 + 0.1 * r(C)
+        sd[bp + f".norms.{i}.bias"] = 0.1 * r(C)
+    x = r(b * f, H, W, C).half()
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(engine, "_FUSED_TEMPORAL", fused)
+        outs[fused] = engine.motion_module(engine.PackedNet(sd, "cpu"), "mm", x, b, f, heads).float()
+    assert rel_err(outs[True], outs[False]) < 2e-3
+    # fp32 restatement of the reference block
+    T, d = H * W, C // heads
+    xs = x.float().reshape(b * f, T, C)
+    h = Fn.group_norm(xs.permute(0, 2, 1), 32, sd[p + ".norm.weight"], sd[p + ".norm.bias"], 1e-6).permute(0, 2, 1)
+    h = h @ sd[p + ".proj_in.weight"].t() + sd[p + ".proj_in.bias"]                        # (b f, T, C)
+    for i in range(2):
+        ap = bp + f".attention_blocks.{i}"
+        nh = Fn.layer_norm(h, (C,), sd[bp + f".norms.{i}.weight"], sd[bp + f".norms.{i}.bias"])
+        t = nh.reshape(b, f, T, C).permute(0, 2, 1, 3).reshape(b * T, f, C) + sd[ap + ".pos_encoder.pe"][:, :f]
+        q, k, v = ((t @ sd[ap + f".{n}.weight"].t()).reshape(b * T, f, heads, d).permute(0, 2, 1, 3) for n in ("to_q", "to_k", "to_v"))
+        o = (torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, -1) @ v).permute(0, 2, 1, 3).reshape(b * T, f, C)
+        o = o @ sd[ap + ".to_out.0.weight"].t() + sd[ap + ".to_out.0.bias"]
+        h = h + o.reshape(b, T, f, C).permute(0, 2, 1, 3).reshape(b * f, T, C)
+    nh = Fn.layer_norm(h, (C,), sd[bp + ".ff_norm.weight"], sd[bp + ".ff_norm.bias"])
+    u = nh @ sd[bp + ".ff.net.0.proj.weight"].t() + sd[bp + ".ff.net.0.proj.bias"]
+    h = h + (u[..., :4 * C] * Fn.gelu(u[..., 4 * C:])) @ sd[bp + ".ff.net.2.weight"].t() + sd[bp + ".ff.net.2.bias"]
+    ref = (h @ sd[p + ".proj_out.weight"].t() + sd[p + ".proj_out.bias"] + xs).reshape(b * f, H, W, C)
+    assert rel_err(outs[True], ref) < TOL

@@ -544,6 +544,54 @@ def test_temporal_attention(B, Fr, T, heads, d):
     close(out, o, f"temporal_attention B{B} F{Fr} T{T} h{heads} d{d}", rtol=4e-3, arms=4e-3)
 
 
+def _tqkv_case(B, T, seed, wscale=1.0, with_pe=True):
+    Fr, C, heads, d = 16, 320, 8, 40
+    M = B * Fr * T
+    x = rnd(M, C, seed=seed, scale=1.7, shift=0.3)
+    gamma = (1.0 + 0.2 * rnd(C, seed=seed + 1).float())
+    beta = 0.1 * rnd(C, seed=seed + 2).float()
+    pe = 0.5 * rnd(Fr, C, seed=seed + 3).float() if with_pe else torch.zeros(Fr, C)
+    wq, wk, wv = (rnd(C, C, seed=seed + 4 + i, scale=wscale * C ** -0.5) for i in range(3))
+    return x, gamma, beta, pe, wq, wk, wv
+
+
+def _tqkv_ref(x, gamma, beta, pe, wq, wk, wv, B, T):
+    """fp32 arithmetic with the fp16 storage points of the three-launch path: normalised rows, q | k | v"""
+    Fr, C, heads, d = 16, 320, 8, 40
+    M = x.shape[0]
+    frame = (torch.arange(M) // T) % Fr
+    nh = (F.layer_norm(x.float(), (C,), gamma, beta, 1e-5) + pe[frame]).half().float()
+    q, k, v = ((nh @ w.float().t()).half().float().reshape(B, Fr, T, heads, d).permute(0, 2, 3, 1, 4).reshape(B * T * heads, Fr, d)
+               for w in (wq, wk, wv))
+    return _attn_ref(q, k, v, d ** -0.5).reshape(B, T, heads, Fr, d).permute(0, 3, 1, 2, 4).reshape(M, C)
+
+
+@pytest.mark.parametrize("B,T,wscale,with_pe", [(1, 8, 1.0, True), (2, 64, 1.0, True), (1, 1032, 1.0, False), (2, 4096, 1.0, True),
+                                                (1, 256, 2.0, True)])
+def test_temporal_qkv_attention_fused(B, T, wscale, with_pe):
+    """csrc/tblock.hip: LayerNorm(+pe) -> to_q / to_k / to_v -> temporal attention in one launch, against fp32 and against the
+    three-launch HIP path it replaces (wscale = 2: logits of standard deviation ~4 — peaky softmax rows.  At wscale = 4, logits
+    ~16, a single flipped fp16 rounding of a q / k element moves a probability by several per cent and 60 of 1.3 M elements
+    left the 4e-3 band on MI355X — for the three-launch path just as well)"""
+    ops = _ops()
+    Fr, C, heads, d = 16, 320, 8, 40
+    assert ops.temporal_qkv_attention_supported(Fr, T, C, heads)
+    assert not ops.temporal_qkv_attention_supported(Fr, T + 4, C, heads) and not ops.temporal_qkv_attention_supported(8, T, C, heads)
+    assert not ops.temporal_qkv_attention_supported(Fr, T, 640, heads)
+    x, gamma, beta, pe, wq, wk, wv = _tqkv_case(B, T, 90, wscale, with_pe)
+    ref = _tqkv_ref(x, gamma, beta, pe, wq, wk, wv, B, T)
+    xd, gd = x.to(DEV), gamma.to(DEV)
+    bpe = (beta[None, :] + pe).contiguous().to(DEV)
+    wp = ops.pack_temporal_qkv(wq.to(DEV), wk.to(DEV), wv.to(DEV))
+    out = ops.temporal_qkv_attention(xd, gd, bpe, wp, B, Fr, T, heads)
+    close(out, ref, f"temporal_qkv_attention B{B} T{T} wscale{wscale}", rtol=4e-3, arms=4e-3)
+    nh = ops.layernorm(xd, gd, beta.to(DEV), pe=pe.contiguous().to(DEV), rows_per_frame=T, frames=Fr)
+    qkv = ops.gemm(nh, torch.cat([wq, wk, wv]).to(DEV))
+    three = ops.temporal_attention(qkv, B, Fr, T, heads, d)
+    close(out, three, f"temporal_qkv_attention vs three launches B{B} T{T}", rtol=4e-3, arms=2e-3)
+    assert torch.equal(out, ops.temporal_qkv_attention(xd, gd, bpe, wp, B, Fr, T, heads)), "not deterministic"
+
+
 # ------------------------------------------------------------------------------------------------
 # small / elementwise
 # ------------------------------------------------------------------------------------------------
@@ -872,6 +920,33 @@ def test_ffn_geglu_fused(M):
     # same rounding points as the two-GEMM path (bit-identical when that path does not split K: tools/exp_ffn.py)
     two = ops.gemm(ops.gemm(x, w1p.to(DEV), b1p.to(DEV), act=1), W2.to(DEV), b2.to(DEV), residual=res.to(DEV))
     close(out, two, f"ffn_geglu fused vs two GEMMs M={M}", rtol=2e-3, arms=1e-3)
+
+
+@pytest.mark.parametrize("M", [128, 4096, 5000, 131072])
+def test_ffn_geglu_fused_with_layernorm_prologue(M):
+    """anip_ffn_geglu_ln: the block's LayerNorm applied while the x tile is staged — against anip_layernorm followed by
+    anip_ffn_geglu (same arithmetic and rounding points; the row sums are formed in another order, so single fp16 roundings of
+    the normalised rows may flip) and against fp32"""
+    ops = _ops()
+    Cc = 320
+    x = rnd(M, Cc, seed=140, scale=1.5, shift=0.2).to(DEV)
+    gamma = (1.0 + 0.2 * rnd(Cc, seed=141).float()).to(DEV)
+    beta = (0.1 * rnd(Cc, seed=142).float()).to(DEV)
+    W1 = rnd(8 * Cc, Cc, seed=131, scale=Cc ** -0.5)
+    b1 = rnd(8 * Cc, seed=132).float()
+    W2 = rnd(Cc, 4 * Cc, seed=133, scale=(4 * Cc) ** -0.5).to(DEV)
+    b2 = rnd(Cc, seed=134).float().to(DEV)
+    w1p, b1p = ops.pack_geglu(W1, b1)
+    w1p, b1p = w1p.to(DEV), b1p.to(DEV)
+    out = ops.ffn_geglu_ln(x, gamma, beta, w1p, b1p, W2, b2, x)
+    two = ops.ffn_geglu(ops.layernorm(x, gamma, beta), w1p, b1p, W2, b2, x)
+    close(out, two, f"ffn_geglu_ln vs layernorm + ffn_geglu M={M}", rtol=2e-3, arms=1e-3)
+    assert torch.equal(out, ops.ffn_geglu_ln(x, gamma, beta, w1p, b1p, W2, b2, x)), "not deterministic"
+    if M <= 5000:
+        n = F.layer_norm(x.float().cpu(), (Cc,), gamma.cpu(), beta.cpu(), 1e-5).half()
+        hv, hg = (_ref_mm(n, W1) + b1).chunk(2, dim=-1)
+        ref = _ref_mm((hv * F.gelu(hg)).half(), W2.cpu()) + b2.cpu() + x.float().cpu()
+        close(out, ref, f"ffn_geglu_ln M={M}", rtol=3e-3, arms=3e-3)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -77,7 +77,25 @@ def norm():
     torch.cuda.synchronize()
 
 
+def fused():
+    """round 5's fused kernels at the 64x64 level: LayerNorm(+pe) -> q|k|v -> temporal attention, LayerNorm -> FFN"""
+    T, C = 4096, 320
+    x = r16(NF * T, C, scale=1.5)
+    g, b = 1 + 0.1 * torch.randn(C, device=DEV), 0.1 * torch.randn(C, device=DEV)
+    bpe = (b[None] + 0.5 * torch.randn(16, C, device=DEV)).contiguous()
+    wp = ops.pack_temporal_qkv(*(r16(C, C, scale=C ** -0.5) for _ in range(3)))
+    for _ in range(REP):
+        ops.temporal_qkv_attention(x, g, bpe, wp, 2, 16, T, 8)
+    w1p, b1p = ops.pack_geglu(r16(8 * C, C, scale=C ** -0.5), torch.randn(8 * C, device=DEV))
+    W2, b2 = r16(C, 4 * C, scale=(4 * C) ** -0.5), torch.randn(C, device=DEV)
+    for _ in range(REP):
+        ops.ffn_geglu_ln(x, g, b, w1p, b1p, W2, b2, x)
+    torch.cuda.synchronize()
+
+
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
+if what in ("fused", "all"):
+    fused()
 if what in ("calib", "all"):
     calib()
 if what in ("attn", "all"):
