@@ -35,7 +35,6 @@ class GemmParams(C.Structure):
         ("trans_out", c_int),
         ("workspace", c_void_p), ("workspace_bytes", c_int64),
         ("head_dim", c_int),
-        ("ln_stats", c_void_p), ("ln_colsum", c_void_p),
     ]
 
 
@@ -54,8 +53,6 @@ SIGNATURES = {
                                c_int, c_void_p]),
     "anip_gemm_workspace_bytes": (c_int64, [C.POINTER(GemmParams)]),
     "anip_gemm": (c_int, [C.POINTER(GemmParams), c_void_p]),
-    "anip_gemm_supports_ln": (c_int, [C.POINTER(GemmParams)]),
-    "anip_row_stats": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "anip_ffn_geglu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                c_void_p]),
     "anip_ffn_geglu_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -74,6 +71,12 @@ SIGNATURES = {
                                       c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int,
                                       c_float, c_int64, c_int64, c_int, c_void_p]),
     "anip_temporal_attention": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "anip_rowgemm320_supported": (c_int, [c_int64, c_int, c_int64]),
+    "anip_ln_qkv_projection": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_float, c_void_p, c_void_p,
+                                       c_int64, c_int64, c_int, c_int, c_void_p]),
+    "anip_groupnorm_scale_shift": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_float,
+                                           c_void_p, c_void_p]),
+    "anip_affine_linear320": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "anip_temporal_qkv_attention_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "anip_temporal_qkv_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                             c_int, c_float, c_float, c_void_p]),

@@ -620,19 +620,18 @@ __global__ __launch_bounds__(NT) void temporal_attn16_kernel(const f16* __restri
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float pr[4];
-    float sum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      pr[r] = __builtin_amdgcn_exp2f((sT[r] - mx) * scale_log2e);
-      sum += pr[r];
-    }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
+    for (int r = 0; r < 4; ++r) pr[r] = __builtin_amdgcn_exp2f((sT[r] - mx) * scale_log2e);
     // ---- P^T as the B operand: lane group 0 / 1 <- keys 0-7, 2 / 3 <- keys 8-15 (the duplicates meet zeros of V^T) ---------
     H2U p01, p23;
     p01.h = __builtin_amdgcn_cvt_pkrtz(pr[0], pr[1]);
     p23.h = __builtin_amdgcn_cvt_pkrtz(pr[2], pr[3]);
+    // the denominator is the sum of the TRUNCATED probabilities the P V product sees (round 5; the fp32 sum of the untruncated
+    // ones biased every output down by up to 2^-11 relative — the reference-attention kernels take it from the same MFMA)
+    float sum = ((float)p01.h[0] + (float)p01.h[1]) + ((float)p23.h[0] + (float)p23.h[1]);
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
     const auto s0 = __builtin_amdgcn_permlane16_swap(p01.u, p01.u, false, false);
     const auto s1 = __builtin_amdgcn_permlane16_swap(p23.u, p23.u, false, false);
     U4H8 pb;

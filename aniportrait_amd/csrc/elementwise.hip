@@ -306,19 +306,25 @@ extern "C" int anip_linear_small(const float* x, const void* W, const float* bia
   ANIP_REQUIRE((K & 7) == 0, "anip_linear_small: K=%d must be a multiple of 8", K);
   const int cols_per_block = (NT / 64) * LS_COLS;
   const int blocks = (N + cols_per_block - 1) / cols_per_block;
-  const size_t lds = (size_t)M * K * sizeof(float);
-  ANIP_REQUIRE(lds <= 65536, "anip_linear_small: M * K = %d * %d floats do not fit in 64 KB of LDS", M, K);
-  {
-    AnipProfScope prof_(ANIP_K_LINEAR_SMALL, (void*)stream);
-    if (M <= 2)
-      hipLaunchKernelGGL(linear_small_kernel<2>, dim3(blocks), dim3(NT), lds, (hipStream_t)stream, x, (const f16*)W, bias, y,
-                         M, N, K, silu_in);
-    else if (M <= 4)
-      hipLaunchKernelGGL(linear_small_kernel<4>, dim3(blocks), dim3(NT), lds, (hipStream_t)stream, x, (const f16*)W, bias, y,
-                         M, N, K, silu_in);
+  // the block stages f(x) of its rows in LDS (64 KB): M * K floats, or — M = 13 .. 16 at K = 1280, a direct UNet forward with a
+  // batch of that size — row chunks of what fits, one launch each
+  ANIP_REQUIRE((size_t)K * sizeof(float) <= 65536, "anip_linear_small: K = %d floats do not fit in 64 KB of LDS", K);
+  const int rows_fit = (int)(65536 / ((size_t)K * sizeof(float)));
+  AnipProfScope prof_(ANIP_K_LINEAR_SMALL, (void*)stream);      // ONE bracket per call (hipops.profile pairs brackets with calls)
+  for (int mb = 0; mb < M; mb += rows_fit) {
+    const int mc = min(rows_fit, M - mb);
+    const size_t lds = (size_t)mc * K * sizeof(float);
+    const float* xc = x + (int64_t)mb * K;
+    float* yc = y + (int64_t)mb * N;
+    if (mc <= 2)
+      hipLaunchKernelGGL(linear_small_kernel<2>, dim3(blocks), dim3(NT), lds, (hipStream_t)stream, xc, (const f16*)W, bias, yc,
+                         mc, N, K, silu_in);
+    else if (mc <= 4)
+      hipLaunchKernelGGL(linear_small_kernel<4>, dim3(blocks), dim3(NT), lds, (hipStream_t)stream, xc, (const f16*)W, bias, yc,
+                         mc, N, K, silu_in);
     else
-      hipLaunchKernelGGL(linear_small_kernel<16>, dim3(blocks), dim3(NT), lds, (hipStream_t)stream, x, (const f16*)W, bias, y,
-                         M, N, K, silu_in);
+      hipLaunchKernelGGL(linear_small_kernel<16>, dim3(blocks), dim3(NT), lds, (hipStream_t)stream, xc, (const f16*)W, bias, yc,
+                         mc, N, K, silu_in);
   }
   ANIP_LAUNCH_CHECK("anip_linear_small");
   return 0;

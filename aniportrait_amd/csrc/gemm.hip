@@ -26,7 +26,6 @@
 int anip_gemm2_try(const anip_gemm_params& p, hipStream_t stream);  // gemm2.hip
 int anip_gemm2_try_splitk(const anip_gemm_params& p, hipStream_t stream);
 int64_t anip_gemm2_workspace_bytes(const anip_gemm_params& p);
-int anip_gemm2_would_take(const anip_gemm_params& p);
 
 namespace {
 
@@ -320,18 +319,6 @@ extern "C" int64_t anip_gemm_workspace_bytes(const anip_gemm_params* pp) {
   return anip_gemm2_workspace_bytes(p);
 }
 
-extern "C" int anip_gemm_supports_ln(const anip_gemm_params* pp) {
-  if (pp == nullptr || pp->M <= 0 || pp->N <= 0 || pp->K <= 0) return 0;
-  anip_gemm_params p = *pp;
-  if (p.batch < 1) p.batch = 1;
-  if (p.alpha == 0.0f) p.alpha = 1.0f;
-  if (p.conv || p.A2 != nullptr || p.batch != 1 || (p.K & 7) != 0 || (p.lda & 7) != 0 || (p.ldw & 7) != 0) return 0;
-  if (!((int64_t)p.M * p.lda * 2 < 0xFFFF0000ll && (int64_t)p.N * p.ldw * 2 < 0xFFFF0000ll)) return 0;
-  static const float dummy[4] = {0.f, 0.f, 0.f, 0.f};
-  if (p.ln_stats == nullptr) p.ln_stats = dummy;      // the dispatch only looks at the pointer being set
-  return anip_gemm2_would_take(p) ? 1 : 0;
-}
-
 extern "C" int anip_gemm(const anip_gemm_params* pp, void* stream) {
   anip_gemm_params p = *pp;
   ANIP_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "anip_gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
@@ -370,13 +357,6 @@ extern "C" int anip_gemm(const anip_gemm_params* pp, void* stream) {
                      p.batch == 1 && !p.conv,
                  "anip_gemm: head-major output needs head_dim %% 8 == 0, N %% head_dim == 0, fp16, plain epilogue (head_dim=%d N=%d)",
                  p.head_dim, p.N);
-  if (p.ln_stats != nullptr) {
-    ANIP_REQUIRE(p.ln_colsum != nullptr && !p.conv && p.A2 == nullptr && p.batch == 1,
-                 "anip_gemm: the LayerNorm fold needs ln_colsum, a plain single-source A and batch 1");
-    ANIP_REQUIRE((((uintptr_t)p.ln_stats) & 7) == 0 && (((uintptr_t)p.ln_colsum) & 15) == 0, "anip_gemm: ln_stats / ln_colsum misaligned");
-    ANIP_REQUIRE(anip_gemm_supports_ln(&p) == 1, "anip_gemm: this problem does not run on the kernel that carries the LayerNorm fold "
-                                                  "(anip_gemm_supports_ln): M=%d N=%d K=%d", p.M, p.N, p.K);
-  }
   const int nbm = (p.M + BM - 1) / BM, nbn = (p.N + BN - 1) / BN;
   dim3 grid((unsigned)(nbm * nbn), (unsigned)p.batch, 1);
   {

@@ -69,7 +69,7 @@ __device__ __forceinline__ void row_swap(float& x, float& y) {
 //     flop drops by 1/4..1/3 and every DMA row is a full 128-B line (BK = 32 rows are half lines), which is what
 //     bounds the smaller tiles (measured: DMA alone = 0.93 ms of the 1.18 ms 8192^3 GEMM).
 //   wide tiles (NST = 2, BK = 64, 8 waves): the quarter-phased main loop (round 3), see "quarter-phased schedule" below.
-template <int BM2, int BN, int NW, int WNW, int BKT, int NST, bool CONV, bool TRANS, bool LNF = false>
+template <int BM2, int BN, int NW, int WNW, int BKT, int NST, bool CONV, bool TRANS>
 __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void gemm2_kernel(const anip_gemm_params p,
                                                                                            const int skip_epilogue, const int splitk) {
   constexpr int NT2 = NW * 64;
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
     // start the accumulators from the per-column additive terms (bias and, when the block's rows share one row group,
     // the row-group bias): NB small L2-resident loads that travel with the prologue DMA, no registers, and nothing
     // left to fetch for them in the epilogue, where loads queue behind the tile's stores (see there).
-    const bool acc_has_bias = !TRANS && splitk <= 1 && p.alpha == 1.0f && !LNF && m0 + BM2 <= p.M && n0 + BN <= p.N &&
+    const bool acc_has_bias = !TRANS && splitk <= 1 && p.alpha == 1.0f && m0 + BM2 <= p.M && n0 + BN <= p.N &&
                               (p.bias != nullptr || p.rowbias != nullptr) &&
                               (p.rowbias == nullptr || (((p.ld_rowbias & 3) == 0) && ((((uintptr_t)p.rowbias) & 15) == 0)));
     const bool rb_uni = acc_has_bias && p.rowbias != nullptr &&
@@ -618,72 +618,8 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
       return;               // (ends a persistent walk, too)
     }
     float alpha = p.alpha;
-    // what the accumulators already carry of the per-column additive terms (see acc_has_bias above, and the fold below)
+    // what the accumulators already carry of the per-column additive terms (see acc_has_bias above)
     bool bias_in_acc = acc_has_bias, rb_in_acc = rb_uni;
-    if constexpr (LNF) {
-      // LayerNorm folded into this GEMM (anip_gemm_params.ln_stats; its own instantiation: the plain kernels carry none of this): A holds the RAW rows x, W carries gamma, and with
-      // (mean, rstd) of every row and s[n] = sum_k W[n][k]
-      //     LN(x) W^T = rstd (x W^T - mean s)      [+ beta W^T + b, which the caller passes as `bias`]
-      // is applied to the finished accumulators — the normalised tensor is never written or read.  Full tiles with 16-B
-      // accessible bias terms take the bias (and a block-uniform row-group bias) in here as well, so that the tight
-      // epilogue below finds them in the accumulators as it does for a plain GEMM.
-      const bool full = m0 + BM2 <= p.M && n0 + BN <= p.N;       // block-uniform
-      const float2* st2 = (const float2*)p.ln_stats;
-      if (!TRANS) {
-        const bool fold = full && (p.bias != nullptr || p.rowbias != nullptr) &&
-                          (p.rowbias == nullptr || (((p.ld_rowbias & 3) == 0) && ((((uintptr_t)p.rowbias) & 15) == 0)));
-        const bool rbu = fold && p.rowbias != nullptr && (m0 / p.rows_per_group == (m0 + BM2 - 1) / p.rows_per_group);
-        const float* rb_row = rbu ? p.rowbias + (int64_t)(m0 / p.rows_per_group) * p.ld_rowbias : nullptr;
-        float ar[FM], br[FM];
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-          const int row = m0 + wm * WTM + i * 16 + fr;
-          const float2 ms = row < p.M ? st2[row] : make_float2(0.f, 0.f);
-          ar[i] = ms.y * alpha;
-          br[i] = -ms.x * ms.y;
-        }
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-          const int cb = n0 + tile_c(j) + fq * 4;
-          f32x4 sc = f32x4{0.f, 0.f, 0.f, 0.f}, b = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (full) {
-            sc = *(const f32x4*)(p.ln_colsum + cb);
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (cb + r < p.N) sc[r] = p.ln_colsum[cb + r];
-          }
-          if (fold && p.bias != nullptr) b = *(const f32x4*)(p.bias + cb);
-          if (rbu) b += *(const f32x4*)(rb_row + cb);
-#pragma unroll
-          for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[i][j][r] = ar[i] * acc[i][j][r] + (br[i] * sc[r] + b[r]);
-        }
-        if (fold) {
-          bias_in_acc = true;
-          rb_in_acc = rbu;
-        }
-      } else {
-        float sj[NB];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-          const int n = n0 + tile_c(j) + fr;
-          sj[j] = n < p.N ? p.ln_colsum[n] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = m0 + wm * WTM + i * 16 + fq * 4 + r;
-            const float2 ms = row < p.M ? st2[row] : make_float2(0.f, 0.f);
-            const float a_ = ms.y * alpha, b_ = -ms.x * ms.y;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) acc[i][j][r] = a_ * acc[i][j][r] + b_ * sj[j];
-          }
-      }
-      alpha = 1.0f;
-    }
     const int64_t obatch = (p.batch > 1) ? (int64_t)blockIdx.y * p.strideO : 0;
     const int tsel = fq & 1, csel = (fq >> 1) * 8;   // after row_swap: tile of the pair / column offset in it
 
@@ -1141,15 +1077,12 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
 
 inline int gemm2_cu_count() { return anip_cu_count(); }   // per device ordinal (api.cpp): partitions of one node may differ
 
-static thread_local bool g_gemm2_dry_run = false;   // anip_gemm2_would_take: walk the dispatch, launch nothing
-
-template <int BM2, int BN, int NW, int WNW, int BKT, int NST, bool CONV, bool TRANS, bool LNF = false>
+template <int BM2, int BN, int NW, int WNW, int BKT, int NST, bool CONV, bool TRANS>
 int launch_gemm2(const anip_gemm_params& p, hipStream_t stream, int splitk = 1) {
   constexpr int NT2 = NW * 64;
-  if (g_gemm2_dry_run) return 1;
   constexpr int LDS = NST * (BM2 + BN) * BKT * 2;
   {
-    auto kfn = gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS, LNF>;
+    auto kfn = gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS>;
     if (anip_raise_lds_limit((const void*)kfn, LDS) != 0) {
       anip_set_error("anip_gemm: cannot raise the dynamic LDS limit to %d bytes", LDS);
       return -2;
@@ -1164,16 +1097,13 @@ int launch_gemm2(const anip_gemm_params& p, hipStream_t stream, int splitk = 1) 
     const unsigned ncu = (unsigned)gemm2_cu_count();
     if (ncu >= 8 && (ncu & 7) == 0 && grid > ncu) grid = ncu;
   }
-  hipLaunchKernelGGL((gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS, LNF>), dim3(grid, (unsigned)p.batch, 1),
+  hipLaunchKernelGGL((gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS>), dim3(grid, (unsigned)p.batch, 1),
                      dim3(NT2), LDS, stream, p, 0, splitk);
   return 1;
 }
 
 template <int BM2, int BN, int NW, int WNW, int BKT, int NST>
 int dispatch_gemm2(const anip_gemm_params& p, hipStream_t stream, int splitk = 1) {
-  if (p.ln_stats != nullptr && !p.conv)      // LayerNorm fold: its own instantiations
-    return p.trans_out ? launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, true, true>(p, stream, splitk)
-                       : launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, false, true>(p, stream, splitk);
   if (p.conv) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, true, false>(p, stream, splitk);
   if (p.trans_out) return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, true>(p, stream, splitk);
   return launch_gemm2<BM2, BN, NW, WNW, BKT, NST, false, false>(p, stream, splitk);
@@ -1233,7 +1163,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // split factor for problems with too few tiles to fill the chip (1 = no split); *cfg = tile configuration:
 // 128 / 160: 128-row 4-wave tiles of that width; 256 / 320: the wide 256-row tiles of that width
 static int gemm2_split(const anip_gemm_params& p, int* cfg) {
-  if (p.ln_stats != nullptr) return 1;     // the reduce pass does not carry the LayerNorm fold
   if (p.batch > 1 || p.act == 1 || p.trans_out || p.M < 64 || p.M > 16384 || (p.N & 3) != 0) return 1;
   if (p.conv ? (p.Cin % 32 != 0) : (p.A2 != nullptr && (p.K1 % 32) != 0)) return 1;
   if ((((uintptr_t)p.bias | (uintptr_t)p.rowbias) & 15) != 0) return 1;
@@ -1301,16 +1230,7 @@ int64_t anip_gemm2_workspace_bytes(const anip_gemm_params& p) {
 
 // split-K path: 1 if launched (partials + reduce), 0 if the problem is not split, < 0 on error
 int anip_gemm2_try(const anip_gemm_params& p, hipStream_t stream);
-// 1 if anip_gemm2_try would run p (the kernel family that carries the LayerNorm fold), without launching anything
-int anip_gemm2_would_take(const anip_gemm_params& p) {
-  g_gemm2_dry_run = true;
-  const int r = anip_gemm2_try(p, nullptr);
-  g_gemm2_dry_run = false;
-  return r == 1;
-}
-
 int anip_gemm2_try_splitk(const anip_gemm_params& p, hipStream_t stream) {
-  if (p.ln_stats != nullptr) return 0;      // the split-K reduce pass does not carry the LayerNorm fold
   int bn = 128;
   const int S = gemm2_split(p, &bn);
   if (S <= 1) return 0;
@@ -1366,9 +1286,7 @@ int anip_gemm2_try(const anip_gemm_params& p, hipStream_t stream) {
   if (k64 && (p.K >= 640 || (p.K >= 256 && p.N >= 320))) {
     const int64_t pad320 = (int64_t)((p.N + 319) / 320) * 320, pad256 = (int64_t)((p.N + 255) / 256) * 256;
     int wbn = 0;
-    // (LayerNorm fold: the 256 x 256 and the 128-row instantiations take its accumulator transform without spilling; the
-    //  256 x 320 / 256 x 160 / 256 x 128 ones, already at their VGPR limit, spill 25-90 dwords in the epilogue and lose 45 %)
-    if (p.act == 1 || p.ln_stats != nullptr) wbn = (pad256 * 100 <= (int64_t)p.N * 115) ? 256 : 0;   // GEGLU pairs tiles: even count per wave
+    if (p.act == 1) wbn = (pad256 * 100 <= (int64_t)p.N * 115) ? 256 : 0;   // GEGLU pairs tiles: even count per wave
     else if (pad320 <= pad256 && pad320 * 100 <= (int64_t)p.N * 115) wbn = 320;
     else if (pad256 * 100 <= (int64_t)p.N * 115) wbn = 256;
     constexpr int wide_min = 192;
@@ -1383,7 +1301,7 @@ int anip_gemm2_try(const anip_gemm_params& p, hipStream_t stream) {
   const int64_t tiles256 = mt256 * ((p.N + bn - 1) / bn) * nb;
   if (tiles256 * 2 < 128) return 0;
   constexpr int big_min = 1024;
-  const bool big = tiles256 >= big_min && p.ln_stats == nullptr;   // >= 2 full rounds of 2 x 256 resident 256-row blocks
+  const bool big = tiles256 >= big_min;   // >= 2 full rounds of 2 x 256 resident 256-row blocks
   if (big) return bn == 128 ? dispatch_gemm2<256, 128, 8, 2, 32, 3>(p, stream) : dispatch_gemm2<256, 160, 8, 2, 32, 3>(p, stream);
   // At most one 128-row tile per CU (the 8x8 level, M = 2048): 64-deep K-tiles and EIGHT waves per tile (wave tile 32 x 64 /
   // 32 x 80).  These launches are bound by what one wave per SIMD can do in order — issue its share of the LDS-DMA, read its

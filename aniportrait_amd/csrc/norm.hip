@@ -378,61 +378,6 @@ __global__ __launch_bounds__(NT) void layernorm_kernel(const f16* __restrict__ x
   }
 }
 
-// (mean, rstd) of every row: the statistics half of layernorm_kernel, for the LayerNorm fold of anip_gemm
-template <int G, int NCH>
-__global__ __launch_bounds__(NT) void row_stats_kernel(const f16* __restrict__ x, int64_t ld, float2* __restrict__ stats, int64_t M,
-                                                      int C, float eps) {
-  constexpr int RPB = NT / G;
-  const int gl = threadIdx.x % G;
-  const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / G;
-  const bool rvalid = row < M;
-  const int CV = C >> 3;
-  const f16* xr = x + (rvalid ? row : 0) * ld;
-  float v[NCH][8];
-  float s = 0.f;
-#pragma unroll
-  for (int k = 0; k < NCH; ++k) {
-    const int cv = gl + G * k;
-    U4H8 t;
-    t.u = u32x4{0u, 0u, 0u, 0u};
-    if (rvalid && cv < CV) t.u = *(const u32x4*)(xr + cv * 8);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      v[k][e] = (float)t.e[e];
-      s += v[k][e];
-    }
-  }
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  const float mean = s / (float)C;
-  float q = 0.f;
-#pragma unroll
-  for (int k = 0; k < NCH; ++k) {
-    const int cv = gl + G * k;
-    if (cv < CV) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float d = v[k][e] - mean;
-        q += d * d;
-      }
-    }
-  }
-#pragma unroll
-  for (int o = G / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-  if (rvalid && gl == 0) stats[row] = make_float2(mean, rsqrtf(q / (float)C + eps));
-}
-
-template <int G>
-void launch_row_stats(int nch, dim3 grid, hipStream_t st, const f16* x, int64_t ld, float2* stats, int64_t M, int C, float eps) {
-  switch (nch) {
-    case 1: hipLaunchKernelGGL((row_stats_kernel<G, 1>), grid, dim3(NT), 0, st, x, ld, stats, M, C, eps); break;
-    case 2: hipLaunchKernelGGL((row_stats_kernel<G, 2>), grid, dim3(NT), 0, st, x, ld, stats, M, C, eps); break;
-    case 3: hipLaunchKernelGGL((row_stats_kernel<G, 3>), grid, dim3(NT), 0, st, x, ld, stats, M, C, eps); break;
-    case 4: hipLaunchKernelGGL((row_stats_kernel<G, 4>), grid, dim3(NT), 0, st, x, ld, stats, M, C, eps); break;
-    default: hipLaunchKernelGGL((row_stats_kernel<G, 5>), grid, dim3(NT), 0, st, x, ld, stats, M, C, eps); break;
-  }
-}
-
 template <int G>
 void launch_layernorm(int nch, dim3 grid, hipStream_t st, const f16* x, const float* gamma, const float* beta, f16* y,
                       int64_t M, int C, float eps, const float* pe, int64_t rpf, int F) {
@@ -468,6 +413,50 @@ __global__ __launch_bounds__(NT) void softmax_rows_kernel(const float* __restric
   sum = red[0] + red[1] + red[2] + red[3];
   const float inv = 1.0f / sum;
   for (int c = tid; c < cols; c += NT) pr[c] = (f16)(__expf(sr[c] - mx) * inv);
+}
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm pass 2 for a consumer that applies the affine form itself (anip_affine_linear320): finalise the statistics of frame
+// n exactly as gn_apply_kernel does and write (scale, shift)[n][c] = (rstd gamma, beta - mean rstd gamma).  grid (N)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void gn_scale_shift_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ out, int C, int64_t HW, int G, float eps,
+                                                           const float* __restrict__ ws, int nchunks) {
+  __shared__ float gmean[NT], grstd[NT], red[2 * NT];
+  const int tid = threadIdx.x, n = blockIdx.x;
+  const int cpg = C / G;
+  const int parts = NT / G;
+  const int part = tid / G, g = tid - part * G;
+  if (part < parts) {
+    float S = 0.f, Q = 0.f;
+    for (int idx = part; idx < nchunks; idx += parts) {
+      const float* o = ws + (((int64_t)n * nchunks + idx) * G + g) * 2;
+      S += o[0];
+      Q += o[1];
+    }
+    red[(part * G + g) * 2] = S;
+    red[(part * G + g) * 2 + 1] = Q;
+  }
+  __syncthreads();
+  if (tid < G) {
+    float S = 0.f, Q = 0.f;
+    for (int pt = 0; pt < parts; ++pt) {
+      S += red[(pt * G + tid) * 2];
+      Q += red[(pt * G + tid) * 2 + 1];
+    }
+    const float cnt = (float)((double)HW * cpg);
+    const float mean = S / cnt;
+    const float var = fmaxf(Q / cnt - mean * mean, 0.f);
+    gmean[tid] = mean;
+    grstd[tid] = rsqrtf(var + eps);
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += NT) {
+    const int gg = c / cpg;
+    const float sc = grstd[gg] * gamma[c];
+    out[((int64_t)n * C + c) * 2] = sc;
+    out[((int64_t)n * C + c) * 2 + 1] = beta[c] - gmean[gg] * sc;
+  }
 }
 
 static void gn_chunks(int N, int64_t HW, int* nchunks, int64_t* ppc) {
@@ -569,6 +558,35 @@ extern "C" int anip_groupnorm_frames(const void* x1, int C1, const void* x2, int
   return 0;
 }
 
+// GroupNorm statistics of x [N][HW][C] -> scale_shift [N][C][2] fp32 = (rstd gamma, beta - mean rstd gamma): the per-frame affine
+// form of InflatedGroupNorm for a consumer that applies it on the fly (anip_affine_linear320).  ws as for anip_groupnorm.
+extern "C" int anip_groupnorm_scale_shift(const void* x, const float* gamma, const float* beta, float* scale_shift, int N,
+                                          int64_t HW, int C, int G, float eps, float* ws, void* stream) {
+  ANIP_REQUIRE(x && gamma && beta && scale_shift && ws, "anip_groupnorm_scale_shift: null pointer");
+  ANIP_REQUIRE(N > 0 && HW > 0 && G > 0 && G <= NT && (C & 7) == 0 && C % G == 0 && C <= 8192,
+               "anip_groupnorm_scale_shift: bad sizes N=%d HW=%lld C=%d G=%d", N, (long long)HW, C, G);
+  int nchunks;
+  int64_t ppc;
+  gn_chunks(N, HW, &nchunks, &ppc);
+  const int CV = C / 8;
+  const int rows_par = CV <= NT ? NT / CV : 1;
+  const size_t sm1 = (size_t)rows_par * C * 2 * sizeof(float);
+  ANIP_REQUIRE(sm1 <= 65536, "anip_groupnorm_scale_shift: stats LDS %zu too large", sm1);
+  {
+    AnipProfScope prof_(ANIP_K_GN_STATS, (void*)stream);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, N), dim3(NT), sm1, (hipStream_t)stream, (const f16*)x, C, (const f16*)nullptr,
+                       0, HW, G, ppc, ws);
+  }
+  ANIP_LAUNCH_CHECK("anip_groupnorm_scale_shift(stats)");
+  {
+    AnipProfScope prof_(ANIP_K_GN_APPLY, (void*)stream);
+    hipLaunchKernelGGL(gn_scale_shift_kernel, dim3(N), dim3(NT), 0, (hipStream_t)stream, gamma, beta, scale_shift, C, HW, G, eps,
+                       (const float*)ws, nchunks);
+  }
+  ANIP_LAUNCH_CHECK("anip_groupnorm_scale_shift(finalise)");
+  return 0;
+}
+
 extern "C" int anip_layernorm(const void* x, const float* gamma, const float* beta, void* y, int64_t M, int C,
                               float eps, const float* pe, int64_t rows_per_frame, int F, void* stream) {
   ANIP_REQUIRE(x && y && gamma && beta, "anip_layernorm: null pointer");
@@ -594,30 +612,6 @@ extern "C" int anip_layernorm(const void* x, const float* gamma, const float* be
     }
   }
   ANIP_LAUNCH_CHECK("anip_layernorm");
-  return 0;
-}
-
-extern "C" int anip_row_stats(const void* x, int64_t ld, float* stats, int64_t M, int C, float eps, void* stream) {
-  ANIP_REQUIRE(x && stats, "anip_row_stats: null pointer");
-  ANIP_REQUIRE(M > 0 && C > 0 && (C & 7) == 0 && C <= LN_MAXCH * 512 && ld >= C && (ld & 7) == 0,
-               "anip_row_stats: bad C=%d / ld=%lld (multiples of 8, C <= %d)", C, (long long)ld, LN_MAXCH * 512);
-  ANIP_REQUIRE((((uintptr_t)x) & 15) == 0 && (((uintptr_t)stats) & 7) == 0, "anip_row_stats: misaligned pointers");
-  const int CV = C / 8;
-  int G = 8;
-  while (G < 64 && (CV + G - 1) / G > LN_MAXCH) G <<= 1;
-  const int nch = (CV + G - 1) / G;
-  const dim3 grid((unsigned)cdiv64(M, NT / G));
-  {
-    AnipProfScope prof_(ANIP_K_LAYERNORM, (void*)stream);
-    hipStream_t st = (hipStream_t)stream;
-    switch (G) {
-      case 8: launch_row_stats<8>(nch, grid, st, (const f16*)x, ld, (float2*)stats, M, C, eps); break;
-      case 16: launch_row_stats<16>(nch, grid, st, (const f16*)x, ld, (float2*)stats, M, C, eps); break;
-      case 32: launch_row_stats<32>(nch, grid, st, (const f16*)x, ld, (float2*)stats, M, C, eps); break;
-      default: launch_row_stats<64>(nch, grid, st, (const f16*)x, ld, (float2*)stats, M, C, eps); break;
-    }
-  }
-  ANIP_LAUNCH_CHECK("anip_row_stats");
   return 0;
 }
 

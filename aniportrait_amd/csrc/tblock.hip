@@ -42,7 +42,11 @@ constexpr int TB_STAGE = 80 * 128;            // 80 weight rows x 64 k
 constexpr int TB_NSTAGES = 60;                // 4 head pairs x {q, k, v} x 5 K-tiles
 constexpr int TB_ORS = 176;                   // bytes per row of the wave-private output staging tile (160 + 16)
 constexpr int TB_OST = TB_NS * TB_STAGE;
-constexpr int TB_LDS = TB_OST + 4 * 32 * TB_ORS;
+// waves per workgroup: 4 = two workgroups per CU whose prologues and tile loops de-phase.  8 (one workgroup per CU, half the
+// LDS-DMA instructions and weight bytes per wave; the kernels are templated on it) measured SLOWER in one call on MI355X:
+// temporal front 111 -> 118 us, q|k|v^T projections 117 -> 124 us, GroupNorm + proj_in 74 -> 80 us (profiles/r05/c_fbench_nw*).
+constexpr int TB_NW = 4;
+constexpr int TB_LDS = TB_OST + TB_NW * 32 * TB_ORS;
 
 struct TbArgs {
   const f16* x;        // [B*16*T][320]
@@ -55,14 +59,15 @@ struct TbArgs {
 };
 
 // (a device function: written inside a lambda, the builtin makes the HOST pass drop the kernel stub silently — see attn_dma.hip)
+template <int NSTAGES, int NW>
 __device__ __forceinline__ void tb_issue_stage(const f16* w, char* smem, int sn, int wave, uint32_t lane_voff) {
-  auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (uint32_t)(960 * TB_C * 2), 0x00020000);
+  auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (uint32_t)((NSTAGES / 5) * 80 * TB_C * 2), 0x00020000);
   const int g = sn / 5, kt = sn - g * 5;
   const uint32_t soff = (uint32_t)(g * (80 * TB_C * 2) + kt * 128);
   char* dst = smem + (sn % TB_NS) * TB_STAGE;
 #pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int j = wave + 4 * i;                // 1-KB piece: weight rows 8 j .. 8 j + 7 of the group
+  for (int i = 0; i < (10 + NW - 1) / NW; ++i) {
+    const int j = wave + NW * i;               // 1-KB piece: weight rows 8 j .. 8 j + 7 of the group
     if (j < 10) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, TB_LDS_PTR(dst + j * 1024), 16, lane_voff + (uint32_t)(j * 8 * TB_C * 2), soff, 0, 0);
   }
 }
@@ -86,7 +91,7 @@ __device__ __forceinline__ f16x8 tb_pack8(const u32x2 lo, const u32x2 hi) {
 // one tile group: acc[j][px] (16 x 16 tiles j = 0..4 of the group's 80 weight rows, pixel px) over the five 64-deep K-tiles
 //   SWAP = false:  D = W x^T   lane (frame = lane & 15, channels 4 (lane >> 4) + r)       (q, k)
 //   SWAP = true:   D = x W^T   lane (channel = lane & 15, frames 4 (lane >> 4) + r)       (v)
-template <bool SWAP>
+template <bool SWAP, int NSTAGES, int NW>
 __device__ __forceinline__ void tb_group(const f16* w, char* smem, int& s, const int wave, const uint32_t lane_voff, const int fr,
                                          const int fq, const f16x8 (&xf)[2][10], f32x4 (&acc)[5][2]) {
 #pragma unroll
@@ -94,12 +99,12 @@ __device__ __forceinline__ void tb_group(const f16* w, char* smem, int& s, const
 #pragma unroll
   for (int kt = 0; kt < 5; ++kt) {
     // this wave's pieces of stage s have landed: everything but the TB_NS - 2 stages issued after it is complete
-    if (s >= TB_NSTAGES - (TB_NS - 2)) TB_VMCNT(0);
-    else if (wave < 2) TB_VMCNT(3 * (TB_NS - 2));
-    else TB_VMCNT(2 * (TB_NS - 2));
+    if (s >= NSTAGES - (TB_NS - 2)) TB_VMCNT(0);
+    else if (wave < 10 % NW) TB_VMCNT(((10 + NW - 1) / NW) * (TB_NS - 2));     // waves that issue one piece more per stage
+    else TB_VMCNT((10 / NW) * (TB_NS - 2));
     __builtin_amdgcn_s_barrier();            // stage s complete for all waves; the slot read at s - 1 is free
     asm volatile("" ::: "memory");
-    if (s + TB_NS - 1 < TB_NSTAGES) tb_issue_stage(w, smem, s + TB_NS - 1, wave, lane_voff);
+    if (s + TB_NS - 1 < NSTAGES) tb_issue_stage<NSTAGES, NW>(w, smem, s + TB_NS - 1, wave, lane_voff);
     const char* st = smem + (s % TB_NS) * TB_STAGE;
     // all ten fragment reads of the stage go out before its first MFMA (left to the scheduler they are issued in pairs right in
     // front of their consumers, every pair's LDS latency exposed)
@@ -125,19 +130,20 @@ __device__ __forceinline__ void tb_group(const f16* w, char* smem, int& s, const
   }
 }
 
-__global__ __launch_bounds__(256, 2) void temporal_qkv_attn_kernel(const TbArgs a) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 8 / NW) void temporal_qkv_attn_kernel(const TbArgs a) {
   constexpr int C = TB_C;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
   const int b = blockIdx.x / a.tpb;
-  const int t0 = (blockIdx.x - b * a.tpb) * 8 + wave * 2;
+  const int t0 = (blockIdx.x - b * a.tpb) * (2 * NW) + wave * 2;
 
   // ---- weight ring: the first TB_NS - 1 stages go out before anything else ------------------------------------------------
   const uint32_t lane_voff = (uint32_t)((lane >> 3) * C * 2 + (((lane & 7) ^ (lane >> 3)) << 4));
 #pragma unroll
-  for (int sn = 0; sn < TB_NS - 1; ++sn) tb_issue_stage(a.w, smem, sn, wave, lane_voff);
+  for (int sn = 0; sn < TB_NS - 1; ++sn) tb_issue_stage<TB_NSTAGES, NW>(a.w, smem, sn, wave, lane_voff);
 
   // ---- the wave's 2 x 16 rows in B-operand layout, LayerNorm + pe in registers ------------------------------------------------
   f16x8 xf[2][10];
@@ -196,12 +202,12 @@ __global__ __launch_bounds__(256, 2) void temporal_qkv_attn_kernel(const TbArgs 
   for (int hp = 0; hp < 4; ++hp) {
     f32x4 acc[5][2];
     u32x2 qp[2][5], kp[2][5];
-    tb_group<false>(a.w, smem, s, wave, lane_voff, fr, fq, xf, acc);
+    tb_group<false, TB_NSTAGES, NW>(a.w, smem, s, wave, lane_voff, fr, fq, xf, acc);
 #pragma unroll
     for (int px = 0; px < 2; ++px)
 #pragma unroll
       for (int j = 0; j < 5; ++j) qp[px][j] = tb_pack4(acc[j][px]);
-    tb_group<false>(a.w, smem, s, wave, lane_voff, fr, fq, xf, acc);
+    tb_group<false, TB_NSTAGES, NW>(a.w, smem, s, wave, lane_voff, fr, fq, xf, acc);
 #pragma unroll
     for (int px = 0; px < 2; ++px)
 #pragma unroll
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void temporal_qkv_attn_kernel(const TbArgs 
       }
     }
 
-    tb_group<true>(a.w, smem, s, wave, lane_voff, fr, fq, xf, acc);
+    tb_group<true, TB_NSTAGES, NW>(a.w, smem, s, wave, lane_voff, fr, fq, xf, acc);
     // ---- O^T = V^T P^T: lane (query fr, channels 16 j + 4 fq + r of the pair), scaled, into the staging tile -------------------
 #pragma unroll
     for (int px = 0; px < 2; ++px) {
@@ -269,6 +275,178 @@ __global__ __launch_bounds__(256, 2) void temporal_qkv_attn_kernel(const TbArgs 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Row-stationary projections at C = 320 (round 5): the same register-resident rows, the same weight ring, no attention —
+//   MODE 0  q | k | v^T = LayerNorm(h) [to_q; to_k; to_v]^T  of a spatial transformer block's attn1 in the three layouts the
+//           reference-attention kernel reads (q token-major x alpha, k head-major, v transposed): one launch instead of
+//           layernorm + three GEMMs (src/models/attention.py:383-401 norm1 -> attn1 projections under
+//           src/models/mutual_self_attention.py:147-186)
+//   MODE 1  out = (x * scale[frame] + shift[frame]) W^T + bias: GroupNorm's affine apply (statistics from gn_stats, finalised
+//           into a per-(frame, channel) table) inside the proj_in 1x1 convolution of Transformer3DModel / the temporal
+//           transformer (src/models/transformer_3d.py:128-139, src/models/motion_module.py:185-204): no gn_apply pass
+// A wave owns 32 consecutive rows, a 256-thread block 128; weights [NG * 80][320] in the caller's row order.
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int RG_VRS = 80;                     // bytes per channel row of the transposed staging tile (64 + 16)
+constexpr int RG_STG = 80 * RG_VRS;            // wave-private staging: max(32 rows x 176 B, 80 channels x 80 B)
+constexpr int RG_LDS = TB_OST + TB_NW * RG_STG;
+
+struct RgArgs {
+  const f16* x;            // [M][320]
+  const float* gamma;      // MODE 0: LayerNorm weight / bias [320]
+  const float* beta;
+  const float* sst;        // MODE 1: [frames][320][2] (scale, shift)
+  int rows_per_frame;      // MODE 1
+  const f16* w;            // [NG * 80][320]
+  const float* bias;       // MODE 1: [320] or null
+  f16* out0;               // MODE 0: q [M][320];  MODE 1: out [M][320]
+  f16* out1;               // MODE 0: k head-major [8][M][40]
+  f16* out2;               // MODE 0: v^T [320][ldvt]
+  int64_t ldvt;
+  int M;
+  float eps, alpha;
+};
+
+template <int MODE, int NW>
+__global__ __launch_bounds__(NW * 64, 8 / NW) void rowgemm320_kernel(const RgArgs a) {
+  constexpr int C = TB_C;
+  constexpr int NG = MODE == 0 ? 12 : 4;
+  constexpr int NSTG = NG * 5;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int m0 = blockIdx.x * (32 * NW) + wave * 32;   // the wave's rows m0 .. m0 + 31 (M % 256 == 0)
+
+  const uint32_t lane_voff = (uint32_t)((lane >> 3) * C * 2 + (((lane & 7) ^ (lane >> 3)) << 4));
+#pragma unroll
+  for (int sn = 0; sn < TB_NS - 1; ++sn) tb_issue_stage<NSTG, NW>(a.w, smem, sn, wave, lane_voff);
+
+  f16x8 xf[2][10];
+  {
+    const f16* xp = a.x + (int64_t)(m0 + fr) * C + fq * 8;
+    U4H8 xr[2][10];
+#pragma unroll
+    for (int px = 0; px < 2; ++px)
+#pragma unroll
+      for (int ks = 0; ks < 10; ++ks) xr[px][ks].u = *(const u32x4*)(xp + px * 16 * C + ks * 32);
+    if constexpr (MODE == 0) {
+      float mean[2], rstd[2];
+#pragma unroll
+      for (int px = 0; px < 2; ++px) {
+        float sm = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 10; ++ks)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) sm += (float)xr[px][ks].e[e];
+        sm += __shfl_xor(sm, 16, 64);
+        sm += __shfl_xor(sm, 32, 64);
+        mean[px] = sm / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 10; ++ks)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = (float)xr[px][ks].e[e] - mean[px];
+            q += d * d;
+          }
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        rstd[px] = rsqrtf(q / (float)C + a.eps);
+      }
+      const float* gp = a.gamma + fq * 8;
+      const float* bp = a.beta + fq * 8;
+#pragma unroll
+      for (int ks = 0; ks < 10; ++ks) {
+        const float4 g0 = *(const float4*)(gp + ks * 32), g1 = *(const float4*)(gp + ks * 32 + 4);
+        const float4 b0 = *(const float4*)(bp + ks * 32), b1 = *(const float4*)(bp + ks * 32 + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+          U4H8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o.e[e] = (f16)(((float)xr[px][ks].e[e] - mean[px]) * rstd[px] * gg[e] + bb[e]);
+          xf[px][ks] = o.h;
+        }
+      }
+    } else {
+      // (scale, shift) of the wave's frame (32 | rows_per_frame): same arithmetic as gn_apply_kernel, x * scale + shift
+      const float* sp = a.sst + ((int64_t)(m0 / a.rows_per_frame) * C + fq * 8) * 2;
+#pragma unroll
+      for (int ks = 0; ks < 10; ++ks) {
+        float4 t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = *(const float4*)(sp + ks * 64 + i * 4);
+        const float sc[8] = {t[0].x, t[0].z, t[1].x, t[1].z, t[2].x, t[2].z, t[3].x, t[3].z};
+        const float sh[8] = {t[0].y, t[0].w, t[1].y, t[1].w, t[2].y, t[2].w, t[3].y, t[3].w};
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+          U4H8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o.e[e] = (f16)((float)xr[px][ks].e[e] * sc[e] + sh[e]);
+          xf[px][ks] = o.h;
+        }
+      }
+    }
+  }
+
+  char* ost = smem + TB_OST + wave * RG_STG;
+  int s = 0;
+#pragma unroll 1
+  for (int g = 0; g < NG; ++g) {
+    f32x4 acc[5][2];
+    const bool trans = MODE == 0 && g >= 8;
+    if (!trans) {
+      tb_group<false, NSTG, NW>(a.w, smem, s, wave, lane_voff, fr, fq, xf, acc);
+      // lane (row fr of pixel group px, columns 16 j + 4 fq + r of the group) -> staging [32 rows][176 B]
+      float bias4[5][4];
+#pragma unroll
+      for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias4[j][r] = (MODE == 1 && a.bias != nullptr) ? a.bias[g * 80 + j * 16 + fq * 4 + r] : 0.f;
+      const float al = (MODE == 0 && g < 4) ? a.alpha : 1.0f;
+#pragma unroll
+      for (int px = 0; px < 2; ++px)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          TbP4 ov;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ov.e[r] = (f16)(acc[j][px][r] * al + bias4[j][r]);
+          *(u32x2*)(ost + (px * 16 + fr) * TB_ORS + j * 32 + fq * 8) = ov.u;
+        }
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int id = i * 64 + lane;
+        const int row = id / 10, pc = id - row * 10;
+        const u32x4 v = *(const u32x4*)(ost + row * TB_ORS + pc * 16);
+        f16* op;
+        if (MODE == 0 && g >= 4) {           // k head-major: head 2 (g - 4) + pc / 5, 40 channels = five 16-B pieces per token
+          const int head = 2 * (g - 4) + pc / 5;
+          op = a.out1 + ((int64_t)head * a.M + m0 + row) * 40 + (pc % 5) * 8;
+        } else {
+          op = a.out0 + (int64_t)(m0 + row) * C + g * 80 + pc * 8;
+        }
+        *(u32x4*)op = v;
+      }
+    } else {
+      tb_group<true, NSTG, NW>(a.w, smem, s, wave, lane_voff, fr, fq, xf, acc);
+      // lane (channel 16 j + fr of the group, rows 16 px + 4 fq + r) -> staging [80 channels][80 B], 64 B = the wave's 32 rows
+#pragma unroll
+      for (int px = 0; px < 2; ++px)
+#pragma unroll
+        for (int j = 0; j < 5; ++j) *(u32x2*)(ost + (j * 16 + fr) * RG_VRS + px * 32 + fq * 8) = tb_pack4(acc[j][px]);
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const int id = i * 64 + lane;
+        const int ch = id >> 2, pc = id & 3;
+        const u32x4 v = *(const u32x4*)(ost + ch * RG_VRS + pc * 16);
+        *(u32x4*)(a.out2 + (int64_t)((g - 8) * 80 + ch) * a.ldvt + m0 + pc * 8) = v;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // LayerNorm(+pe) -> [to_q; to_k; to_v] -> temporal self-attention over F = 16 frames at C = 320 (8 heads x 40), one launch.
@@ -284,14 +462,14 @@ extern "C" int anip_temporal_qkv_attention(const void* x, const float* gamma, co
                "anip_temporal_qkv_attention: pointers must be 16-B aligned");
   TbArgs a;
   a.x = (const f16*)x; a.gamma = gamma; a.bpe = beta_pe; a.w = (const f16*)w_packed; a.out = (f16*)out;
-  a.T = T; a.tpb = T / 8; a.eps = eps; a.scale_log2e = scale * 1.4426950408889634f;
-  if (anip_raise_lds_limit((const void*)temporal_qkv_attn_kernel, TB_LDS) != 0) {
+  a.T = T; a.tpb = T / (2 * TB_NW); a.eps = eps; a.scale_log2e = scale * 1.4426950408889634f;
+  if (anip_raise_lds_limit((const void*)temporal_qkv_attn_kernel<TB_NW>, TB_LDS) != 0) {
     anip_set_error("anip_temporal_qkv_attention: cannot raise the dynamic LDS limit to %d bytes", TB_LDS);
     return -2;
   }
   {
     AnipProfScope prof_(ANIP_K_GEMM, stream);
-    hipLaunchKernelGGL(temporal_qkv_attn_kernel, dim3((unsigned)(B * (T / 8))), dim3(256), TB_LDS, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(temporal_qkv_attn_kernel<TB_NW>, dim3((unsigned)(B * a.tpb)), dim3(TB_NW * 64), TB_LDS, (hipStream_t)stream, a);
   }
   ANIP_LAUNCH_CHECK("anip_temporal_qkv_attention");
   return 0;
@@ -299,4 +477,58 @@ extern "C" int anip_temporal_qkv_attention(const void* x, const float* gamma, co
 
 extern "C" int anip_temporal_qkv_attention_supported(int F, int T, int C, int heads) {
   return (F == 16 && C == TB_C && heads == 8 && T > 0 && (T % 8) == 0) ? 1 : 0;
+}
+
+extern "C" int anip_rowgemm320_supported(int64_t M, int C, int64_t rows_per_frame) {
+  return (C == TB_C && M > 0 && (M % 128) == 0 && M * (int64_t)TB_C * 2 < (1ll << 40) && (rows_per_frame == 0 || rows_per_frame % 32 == 0))
+             ? 1 : 0;
+}
+
+// LayerNorm(x) -> q (token-major, x alpha) | k (head-major [heads][M][40]) | v^T ([320][ldvt]) at C = 320, 8 heads, one launch
+extern "C" int anip_ln_qkv_projection(const void* x, const float* gamma, const float* beta, float eps, const void* w_qkv,
+                                      void* q, float q_alpha, void* k_head_major, void* vt, int64_t ldvt, int64_t M, int C,
+                                      int heads, void* stream) {
+  ANIP_REQUIRE(x && gamma && beta && w_qkv && q && k_head_major && vt, "anip_ln_qkv_projection: null pointer");
+  ANIP_REQUIRE(heads == 8 && anip_rowgemm320_supported(M, C, 0) == 1 && M < (1ll << 31) && ldvt >= M && (ldvt & 7) == 0,
+               "anip_ln_qkv_projection: only C = 320, heads = 8, M %% 128 == 0, ldvt %% 8 == 0 is built (M=%lld C=%d heads=%d)",
+               (long long)M, C, heads);
+  ANIP_REQUIRE((((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)w_qkv | (uintptr_t)q | (uintptr_t)k_head_major |
+                 (uintptr_t)vt) & 15) == 0, "anip_ln_qkv_projection: pointers must be 16-B aligned");
+  RgArgs a = {};
+  a.x = (const f16*)x; a.gamma = gamma; a.beta = beta; a.w = (const f16*)w_qkv;
+  a.out0 = (f16*)q; a.out1 = (f16*)k_head_major; a.out2 = (f16*)vt; a.ldvt = ldvt; a.M = (int)M; a.eps = eps; a.alpha = q_alpha;
+  if (anip_raise_lds_limit((const void*)rowgemm320_kernel<0, TB_NW>, RG_LDS) != 0) {
+    anip_set_error("anip_ln_qkv_projection: cannot raise the dynamic LDS limit to %d bytes", RG_LDS);
+    return -2;
+  }
+  {
+    AnipProfScope prof_(ANIP_K_GEMM, stream);
+    hipLaunchKernelGGL((rowgemm320_kernel<0, TB_NW>), dim3((unsigned)(M / (32 * TB_NW))), dim3(TB_NW * 64), RG_LDS, (hipStream_t)stream, a);
+  }
+  ANIP_LAUNCH_CHECK("anip_ln_qkv_projection");
+  return 0;
+}
+
+// out = (x * scale[frame] + shift[frame]) W^T + bias at C = 320 -> 320: GroupNorm's apply inside the following 1x1 convolution
+extern "C" int anip_affine_linear320(const void* x, const float* scale_shift, int64_t rows_per_frame, const void* w,
+                                     const float* bias, void* out, int64_t M, int C, void* stream) {
+  ANIP_REQUIRE(x && scale_shift && w && out, "anip_affine_linear320: null pointer");
+  ANIP_REQUIRE(rows_per_frame > 0 && anip_rowgemm320_supported(M, C, rows_per_frame) == 1 && M % rows_per_frame == 0 && M < (1ll << 31),
+               "anip_affine_linear320: only C = 320, M %% 128 == 0, rows_per_frame %% 32 == 0 is built (M=%lld C=%d rows_per_frame=%lld)",
+               (long long)M, C, (long long)rows_per_frame);
+  ANIP_REQUIRE((((uintptr_t)x | (uintptr_t)scale_shift | (uintptr_t)w | (uintptr_t)out) & 15) == 0 && (((uintptr_t)bias) & 3) == 0,
+               "anip_affine_linear320: pointers must be 16-B aligned");
+  RgArgs a = {};
+  a.x = (const f16*)x; a.sst = scale_shift; a.rows_per_frame = (int)rows_per_frame; a.w = (const f16*)w; a.bias = bias;
+  a.out0 = (f16*)out; a.M = (int)M; a.alpha = 1.0f;
+  if (anip_raise_lds_limit((const void*)rowgemm320_kernel<1, TB_NW>, RG_LDS) != 0) {
+    anip_set_error("anip_affine_linear320: cannot raise the dynamic LDS limit to %d bytes", RG_LDS);
+    return -2;
+  }
+  {
+    AnipProfScope prof_(ANIP_K_GEMM, stream);
+    hipLaunchKernelGGL((rowgemm320_kernel<1, TB_NW>), dim3((unsigned)(M / (32 * TB_NW))), dim3(TB_NW * 64), RG_LDS, (hipStream_t)stream, a);
+  }
+  ANIP_LAUNCH_CHECK("anip_affine_linear320");
+  return 0;
 }

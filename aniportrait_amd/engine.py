@@ -124,24 +124,6 @@ class PackedNet:
             self.t[k] = ops.pack_geglu(w, b)
         return self.t[k]
 
-    def ln_lin(self, wnames, bname, norm, alpha=1.0, geglu=False):
-        """nn.LayerNorm `norm` folded into the Linear it feeds (ops.fold_layernorm): (W gamma fp16, column sums fp32, beta W^T +
-        bias fp32), the weights being the row-concatenation of `wnames` (the temporal attention's [to_q; to_k; to_v])"""
-        k = ("lnlin", tuple(wnames), bname, norm, float(alpha), bool(geglu))
-        if k not in self.t:
-            W = torch.cat([self._raw(n).to(self.device, F32).reshape(self.sd[n].shape[0], -1) for n in wnames], dim=0)
-            b = self._raw(bname).to(self.device, F32) if bname is not None else None
-            self.t[k] = ops.fold_layernorm(W, b, self.f32(norm + ".weight"), self.f32(norm + ".bias"), alpha=alpha, geglu=geglu)
-        return self.t[k]
-
-    def pe_rowbias(self, pe_name, wnames, C, b, f):
-        """(LN(x) + pe[frame]) W^T = LN(x) W^T + pe[frame] W^T: the second term as a row-group bias table fp32 [b f][N]"""
-        k = ("perb", pe_name, tuple(wnames), int(b), int(f))
-        if k not in self.t:
-            W = torch.cat([self._raw(n).to(self.device, F16) for n in wnames], dim=0).float()
-            self.t[k] = (self.pe(pe_name, C)[:f] @ W.t()).repeat(b, 1).contiguous()
-        return self.t[k]
-
     def pe(self, name, C):
         """positional-encoding table fp32 [max_len][C]"""
         k = ("pe", name)
@@ -233,37 +215,30 @@ _FUSED_FFN = os.environ.get("ANIP_FUSED_FFN", "1") == "1"
 _FFN_LN = os.environ.get("ANIP_FFN_LN", "1") == "1"
 
 
-# nn.LayerNorm folded into the GEMM it feeds (anip_gemm_params.ln_stats): the consumer reads the raw rows, gamma sits in its
-# weights and the mean / rstd correction is applied to its accumulators — the normalised tensor (84 MB at the 64x64 level)
-# is neither written nor read, one statistics pass over the rows replaces the LayerNorm kernel.  Parity-green, and OFF:
-# measured on MI355X inside one call each (profiles/r04/n_*): the LayerNorm family drops 49 -> 29 ms per clip, but the consuming
-# GEMMs gain more than that (657 -> 695 ms: the temporal qkv projection at 64x64 128 -> 219 us, the C = 640 GEGLU 243 -> 265 us)
-# — their K = 320 .. 1280 main loops are short, and the extra dependent loads of the accumulator transform sit exposed in front
-# of the stores.  ANIP_LN_FOLD=1 selects it (A/B measurements, tests).
-_LN_FOLD = os.environ.get("ANIP_LN_FOLD", "0") == "1"
-
 # LayerNorm(+pe) -> to_q / to_k / to_v -> temporal attention as ONE launch at C = 320, F = 16 (csrc/tblock.hip): the normalised
 # rows and the M x 960 q|k|v matrix never reach HBM.  ANIP_FUSED_TEMPORAL=0 selects the three-launch path (A/B measurements).
 _FUSED_TEMPORAL = os.environ.get("ANIP_FUSED_TEMPORAL", "1") == "1"
-_ln_ok_cache = {}
+# row-stationary projections at C = 320 (csrc/tblock.hip): norm1 -> to_q | to_k | to_v^T as one launch, and GroupNorm's apply
+# inside proj_in (statistics finalised into a per-frame affine table).  ANIP_FUSED_ROWS=0 selects the separate launches.
+_FUSED_ROWS = os.environ.get("ANIP_FUSED_ROWS", "1") == "1"
 
 
-def _ln_ok(M, N, K, **kw):
-    key = (M, N, K, tuple(sorted(kw.items())))
-    if key not in _ln_ok_cache:
-        _ln_ok_cache[key] = _LN_FOLD and ops.gemm_supports_ln(M, N, K, **kw)
-    return _ln_ok_cache[key]
-
-
+def transformer_in(net, p, x):
+    """norm (GroupNorm 32, eps 1e-6, no activation) -> proj_in of Transformer3DModel / the temporal transformer
+    (src/models/transformer_3d.py:128-139, src/models/motion_module.py:185-204; also the PoseGuider's Transformer2DModel,
+    whose proj_in widens 320 -> 16 x 88 and therefore stays on the two launches): x (N, H, W, C) -> h (N*H*W, inner)"""
+    N, H, W, C = x.shape
+    T = H * W
+    if _FUSED_ROWS and net.lin(p + ".proj_in.weight").shape[0] == C and ops.rowgemm320_supported(N * T, C, T):
+        sst = ops.groupnorm_scale_shift(x.reshape(N, T, C), net.f32(p + ".norm.weight"), net.f32(p + ".norm.bias"), 32, 1e-6)
+        return ops.affine_linear320(x.reshape(N * T, C), sst, T, net.lin(p + ".proj_in.weight"), net.f32(p + ".proj_in.bias"))
+    h = ops.groupnorm(x.reshape(N, T, C), net.f32(p + ".norm.weight"), net.f32(p + ".norm.bias"), 32, 1e-6, False)
+    return ops.gemm(h.reshape(N * T, C), net.lin(p + ".proj_in.weight"), net.f32(p + ".proj_in.bias"))
 def feed_forward(net, p, h, norm):
     """LayerNorm `norm` -> diffusers FeedForward(geglu) -> + h (src/models/attention.py:361,436-445,
     src/models/motion_module.py:233-234,256-257): GEGLU fused in the first GEMM's epilogue."""
     M, C = h.shape
     fused = _FUSED_FFN and C == 320 and net.has(p + ".net.2.bias")
-    if not fused and _ln_ok(M, 8 * C, C, act=1):
-        wp, cs, bp = net.ln_lin((p + ".net.0.proj.weight",), p + ".net.0.proj.bias", norm, geglu=True)
-        g = ops.gemm(h, wp, bp, act=1, ln=(ops.row_stats(h), cs))
-        return ops.gemm(g, net.lin(p + ".net.2.weight"), net.f32(p + ".net.2.bias"), residual=h)
     wp, bp = net.geglu(p + ".net.0.proj")
     if fused and _FFN_LN:
         return ops.ffn_geglu_ln(h, net.f32(norm + ".weight"), net.f32(norm + ".bias"), wp, bp, net.lin(p + ".net.2.weight"),
@@ -345,14 +320,9 @@ def transformer_block(net, p, h, Nf, T, heads, attn2_vec, rows_per_sample, ref=N
     # attention kernel's K-tile reads touch 2-3x the cache lines (measured at 64x64, d = 40: 1.75 ms fused rows, 1.60 ms
     # separate matrices, 1.54 ms contiguous rows — against +12 us for the second GEMM launch); V transposed [C][Nf*T]
     wq, wk, wv = p + ".attn1.to_q.weight", p + ".attn1.to_k.weight", p + ".attn1.to_v.weight"
-    if mode != "write" and _ln_ok(M, C, C) and _ln_ok(M, C, C, head_dim=d) and _ln_ok(M, C, C, trans_out=True):
-        st = ops.row_stats(h)                       # norm1 folded into the three projections
-        Wq, sq, bq = net.ln_lin((wq,), None, p + ".norm1", alpha=qa)
-        Wk, sk, bk = net.ln_lin((wk,), None, p + ".norm1")
-        Wv, sv, bv = net.ln_lin((wv,), None, p + ".norm1")
-        q = ops.gemm(h, Wq, bq, alpha=qa, ln=(st, sq))
-        k = ops.gemm(h, Wk, bk, head_dim=d, ln=(st, sk))
-        vt = ops.gemm(h, Wv, bv, trans_out=True, ln=(st, sv))
+    if mode != "write" and heads == 8 and _FUSED_ROWS and ops.rowgemm320_supported(M, C):
+        q, k, vt = ops.ln_qkv_projection(h, net.f32(p + ".norm1.weight"), net.f32(p + ".norm1.bias"), net.cat_lin((wq, wk, wv)),
+                                         heads, qa)
     else:
         nh = ops.layernorm(h, net.f32(p + ".norm1.weight"), net.f32(p + ".norm1.bias"))
         if mode == "write":
@@ -381,8 +351,7 @@ def spatial_transformer(net, p, x, heads, attn2_vec, frames_per_sample, ref=None
     """Transformer3DModel / Transformer2DModel (src/models/transformer_3d.py:103-169): x (N,H,W,C)."""
     N, H, W, C = x.shape
     T = H * W
-    h = ops.groupnorm(x.reshape(N, T, C), net.f32(p + ".norm.weight"), net.f32(p + ".norm.bias"), 32, 1e-6, False)
-    h = ops.gemm(h.reshape(N * T, C), net.lin(p + ".proj_in.weight"), net.f32(p + ".proj_in.bias"))
+    h = transformer_in(net, p, x)
     h = transformer_block(net, p + ".transformer_blocks.0", h, N, T, heads, attn2_vec, frames_per_sample * T,
                           ref, ref_index, stop_after_bank)
     if h is None:
@@ -397,8 +366,7 @@ def motion_module(net, p, x, b, f, heads):
     N, H, W, C = x.shape
     T = H * W
     d = C // heads
-    h = ops.groupnorm(x.reshape(N, T, C), net.f32(p + ".norm.weight"), net.f32(p + ".norm.bias"), 32, 1e-6, False)
-    h = ops.gemm(h.reshape(N * T, C), net.lin(p + ".proj_in.weight"), net.f32(p + ".proj_in.bias"))
+    h = transformer_in(net, p, x)
     bp = p + ".transformer_blocks.0"
     i = 0
     while net.has(bp + f".attention_blocks.{i}.to_q.weight"):
@@ -417,15 +385,9 @@ def motion_module(net, p, x, b, f, heads):
             h = ops.gemm(a, net.lin(ap + ".to_out.0.weight"), net.f32(ap + ".to_out.0.bias"), residual=h)
             i += 1
             continue
-        if _ln_ok(N * T, 3 * C, C):
-            # folded: (LN(h) + pe_f) W^T = rstd (h W'^T - mean s) + beta W^T + pe_f W^T, the last term a per-frame row bias
-            Wf, cs, bf = net.ln_lin(wn, None, bp + f".norms.{i}")
-            rb = net.pe_rowbias(pe_name, wn, C, b, f) if pe is not None else None
-            qkv = ops.gemm(h, Wf, bf, rowbias=rb, rows_per_group=T if rb is not None else 0, ln=(ops.row_stats(h), cs))
-        else:
-            nh = ops.layernorm(h, net.f32(bp + f".norms.{i}.weight"), net.f32(bp + f".norms.{i}.bias"), pe=pe,
-                               rows_per_frame=T, frames=f)
-            qkv = ops.gemm(nh, net.cat_lin(wn))
+        nh = ops.layernorm(h, net.f32(bp + f".norms.{i}.weight"), net.f32(bp + f".norms.{i}.bias"), pe=pe,
+                           rows_per_frame=T, frames=f)
+        qkv = ops.gemm(nh, net.cat_lin(wn))
         a = ops.temporal_attention(qkv, b, f, T, heads, d)
         h = ops.gemm(a, net.lin(ap + ".to_out.0.weight"), net.f32(ap + ".to_out.0.bias"), residual=h)
         i += 1
@@ -712,8 +674,7 @@ def _pose_self_attn(net, p, x, heads=16):
     Its second argument (ref_x) never reaches the arithmetic (no attn2), so it is not evaluated."""
     N, H, W, C = x.shape
     T = H * W
-    h = ops.groupnorm(x.reshape(N, T, C), net.f32(p + ".norm.weight"), net.f32(p + ".norm.bias"), 32, 1e-6, False)
-    h = ops.gemm(h.reshape(N * T, C), net.lin(p + ".proj_in.weight"), net.f32(p + ".proj_in.bias"))
+    h = transformer_in(net, p, x)
     h = transformer_block(net, p + ".transformer_blocks.0", h, N, T, heads, None, 0)
     out = ops.gemm(h, net.lin(p + ".proj_out.weight"), net.f32(p + ".proj_out.bias"), residual=x.reshape(N * T, C))
     return out.reshape(N, H, W, C)

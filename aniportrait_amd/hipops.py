@@ -264,6 +264,59 @@ def groupnorm(x1, gamma, beta, groups, eps, silu, x2=None, frames_per_stat=1):
     return y
 
 
+def rowgemm320_supported(M, C, rows_per_frame=0):
+    return bool(L.load().anip_rowgemm320_supported(int(M), int(C), int(rows_per_frame)))
+
+
+def groupnorm_scale_shift(x, gamma, beta, groups, eps):
+    """per-frame GroupNorm statistics of x (N, HW, C) finalised into the affine form (N, C, 2) fp32 = (rstd gamma,
+    beta - mean rstd gamma) for affine_linear320"""
+    lib = L.load()
+    _req(x, F16, "x")
+    N, HW, Cc = x.shape
+    ws = torch.empty((lib.anip_groupnorm_ws_floats(N, HW, Cc, groups),), dtype=F32, device=x.device)
+    out = torch.empty((N, Cc, 2), dtype=F32, device=x.device)
+    _work(K_GN_STATS, N * HW * Cc * 2, f"N{N} HW{HW} C{Cc}")
+    _work(K_GN_APPLY, N * Cc * 8, f"N{N} C{Cc} scale_shift")
+    L.check(lib.anip_groupnorm_scale_shift(_p(x), _p(_req(gamma, F32, "gamma")), _p(_req(beta, F32, "beta")), _p(out), N, HW,
+                                           Cc, groups, float(eps), _p(ws), _stream()), "anip_groupnorm_scale_shift")
+    return out
+
+
+def affine_linear320(x, scale_shift, rows_per_frame, W, bias=None):
+    """(x * scale[frame] + shift[frame]) W^T + bias at C = 320 -> 320 (anip_affine_linear320): x (M, 320) fp16, scale_shift
+    (frames, 320, 2) fp32, W (320, 320) fp16"""
+    lib = L.load()
+    _req(x, F16, "x")
+    _req(W, F16, "W")
+    M, Cc = x.shape
+    assert tuple(W.shape) == (Cc, Cc) and scale_shift.shape[0] * rows_per_frame == M
+    out = torch.empty_like(x)
+    _work(K_GEMM, 2 * M * Cc * Cc, f"affine_linear M{M} C{Cc}", M * Cc * 2 * 2 + Cc * Cc * 2)
+    L.check(lib.anip_affine_linear320(_p(x), _p(_req(scale_shift, F32, "scale_shift")), int(rows_per_frame), _p(W), _p(bias),
+                                      _p(out), M, Cc, _stream()), "anip_affine_linear320")
+    return out
+
+
+def ln_qkv_projection(x, gamma, beta, w_qkv, heads, q_alpha, eps=1e-5):
+    """LayerNorm(x) -> (q token-major x q_alpha (M, C), k head-major (heads, M, d), v^T (C, M)) in one launch
+    (anip_ln_qkv_projection; C = 320, 8 heads): w_qkv (3C, C) fp16 = [to_q; to_k; to_v]"""
+    lib = L.load()
+    _req(x, F16, "x")
+    _req(w_qkv, F16, "w_qkv")
+    M, Cc = x.shape
+    d = Cc // heads
+    assert tuple(w_qkv.shape) == (3 * Cc, Cc)
+    q = torch.empty((M, Cc), dtype=F16, device=x.device)
+    k = torch.empty((heads, M, d), dtype=F16, device=x.device)
+    vt = torch.empty((Cc, M), dtype=F16, device=x.device)
+    _work(K_GEMM, 2 * M * 3 * Cc * Cc, f"ln_qkv M{M} C{Cc}", M * Cc * 2 * 4 + 3 * Cc * Cc * 2)
+    L.check(lib.anip_ln_qkv_projection(_p(x), _p(_req(gamma, F32, "gamma")), _p(_req(beta, F32, "beta")), float(eps),
+                                       _p(w_qkv), _p(q), float(q_alpha), _p(k), _p(vt), M, M, Cc, heads, _stream()),
+            "anip_ln_qkv_projection")
+    return q, k, vt
+
+
 def layernorm(x, gamma, beta, eps=1e-5, pe=None, rows_per_frame=0, frames=0):
     lib = L.load()
     _req(x, F16, "x")
@@ -276,7 +329,7 @@ def layernorm(x, gamma, beta, eps=1e-5, pe=None, rows_per_frame=0, frames=0):
 
 
 def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None, act=0, out_f32=False,
-         alpha=1.0, out=None, conv=None, batch=1, ldo=None, ldr=None, trans_out=False, head_dim=0, debug_ws=None, ln=None):
+         alpha=1.0, out=None, conv=None, batch=1, ldo=None, ldr=None, trans_out=False, head_dim=0, debug_ws=None):
     """out = epilogue(alpha * A @ W^T).
 
     A (M, K) fp16 [+ A2 (M, K2): K split over two sources]; W (N, K) fp16; bias (N,) fp32;
@@ -287,8 +340,6 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
     batch > 1: A (B, M, K) or (M, K) shared; W (B, N, K) or (N, K) shared -> out (B, M, N).
     trans_out: return the transposed result (N, M) (bias only, fp16).
     head_dim > 0: head-major result (N / head_dim, M, head_dim): each head's rows contiguous (K of ref_attention).
-    ln=(stats, colsum): LayerNorm folded in (anip_gemm_params.ln_stats): A = the raw rows, W = fold_layernorm's weights,
-    stats = row_stats(A), colsum = fold_layernorm's column sums, bias = its folded bias.
     """
     lib = L.load()
     p = L.GemmParams()
@@ -358,12 +409,6 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
             raise TypeError("residual: expected fp16")
         p.residual, p.ldr = _p(residual), int(ldr if ldr is not None else n_out)
     p.act = int(act)
-    if ln is not None:
-        stats, colsum = ln
-        _req(stats, F32, "ln stats")
-        _req(colsum, F32, "ln colsum")
-        assert stats.numel() == 2 * M and colsum.numel() == N and conv is None and A2 is None and not batched
-        p.ln_stats, p.ln_colsum = _p(stats), _p(colsum)
     if _WORK is not None:
         if conv is not None:
             desc = (f"N{conv['Nimg']} {conv['Hin']}x{conv['Win']} Cin{conv['Cin']} Cout{N} s{conv['stride']}"
@@ -373,7 +418,7 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
             desc = (f"M{M} N{N} K{K}{' b%d' % batch if batched else ''}{' geglu' if act == 1 else ''}"
                     f"{' A2' if A2 is not None else ''}{' rb' if rowbias is not None else ''}"
                     f"{' res' if residual is not None else ''}{' T' if trans_out else ''}{' f32' if out_f32 else ''}"
-                    f"{' hm' if head_dim else ''}{' ln' if ln is not None else ''}")
+                    f"{' hm' if head_dim else ''}")
         nb = max(1, int(p.batch))
         a_bytes = (conv["Nimg"] * conv["Hin"] * conv["Win"] * conv["Cin"] if conv is not None else
                    M * K * (nb if (not batched or A.dim() == 3) else 1)) * 2
@@ -389,45 +434,6 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
         p.workspace, p.workspace_bytes = _p(debug_ws), debug_ws.numel() * debug_ws.element_size()
     L.check(lib.anip_gemm(C.byref(p), _stream()), "anip_gemm")
     return out
-
-
-def row_stats(x, eps=1e-5):
-    """(mean, rstd) fp32 pairs of the rows of x (M, C) fp16: the statistics of nn.LayerNorm(C, eps) for gemm(ln=...)"""
-    lib = L.load()
-    _req(x, F16, "x")
-    M, Cc = x.shape
-    stats = torch.empty((M, 2), dtype=F32, device=x.device)
-    _work(K_LAYERNORM, M * Cc * 2, f"row_stats M{M} C{Cc}")
-    L.check(lib.anip_row_stats(_p(x), x.stride(0), _p(stats), M, Cc, float(eps), _stream()), "anip_row_stats")
-    return stats
-
-
-def gemm_supports_ln(M, N, K, act=0, trans_out=False, head_dim=0, lda=None, ldw=None):
-    """whether gemm(ln=...) of this shape runs on the kernel that carries the LayerNorm fold (anip_gemm_supports_ln)"""
-    lib = L.load()
-    p = L.GemmParams()
-    p.M, p.N, p.K, p.batch, p.act = int(M), int(N), int(K), 1, int(act)
-    p.lda, p.ldw = int(lda if lda is not None else K), int(ldw if ldw is not None else K)
-    p.trans_out, p.head_dim, p.alpha = int(bool(trans_out)), int(head_dim), 1.0
-    return bool(lib.anip_gemm_supports_ln(C.byref(p)))
-
-
-def fold_layernorm(W, bias, gamma, beta, alpha=1.0, geglu=False):
-    """weights of `LayerNorm(gamma, beta) -> Linear(W, bias)` for gemm(ln=...): (W' = W gamma  fp16, colsum = alpha sum_k W'
-    fp32, bias' = alpha (W beta + bias) fp32).  W (N, K) fp16 / fp32, gamma / beta (K,) fp32.  alpha: the GEMM's alpha
-    (the kernel multiplies the accumulators by it; the additive terms carry it here).  geglu: pack W' / the vectors with
-    pack_geglu afterwards (rows per 32 as [16 value | 16 gate])."""
-    Wf = W.float() * gamma.float()[None, :]
-    Wh = Wf.half()
-    colsum = Wh.float().sum(dim=1) * alpha
-    b = W.float() @ beta.float()
-    if bias is not None:
-        b = b + bias.float()
-    b = b * alpha
-    if geglu:
-        _, colsum = pack_geglu(Wh, colsum)
-        Wh, b = pack_geglu(Wh, b)
-    return Wh.contiguous(), colsum.contiguous().float(), b.contiguous().float()
 
 
 def ffn_geglu(x, w1p, b1p, w2, b2, residual=None):

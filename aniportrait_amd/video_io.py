@@ -1,7 +1,10 @@
 """Output side of the path: what the reference's scripts do with the frames the pipeline returns —
-`save_videos_grid` and `save_videos_from_pil` (/root/reference/src/utils/util.py:51-104).  Every other name of that module
-(the PyAV readers, the training scripts' host helpers, `crop_face`) is out of the path's scope and keeps coming from the
-reference's own file through the `src/utils/util.py` shim.
+`save_videos_grid` and `save_videos_from_pil` (/root/reference/src/utils/util.py:51-104) — and the three small helpers every
+inference script imports next to them for the INPUT side, `read_frames`, `get_fps` (the pose video, util.py:107-130) and
+`seed_everything` (util.py:17-25), so that `from src.utils.util import ...` at the top of scripts/pose2vid.py / vid2vid.py /
+audio2vid.py resolves without executing the reference's util.py (which imports cv2, torchvision and einops at module level).
+PyAV is imported on first use.  What is left to the reference's own file through the `src/utils/util.py` shim: the training
+scripts' host helpers (`import_filename`, `delete_additional_ckpt`) and `crop_face` — outside the path's scope.
 
 The reference builds every output frame on the host in fp32: `torchvision.utils.make_grid` of the (b, 3, h, w) batch of
 one time step, two transposes, `(x * 255).numpy().astype(uint8)`, `Image.fromarray` — per frame, in a Python loop
@@ -97,3 +100,29 @@ def save_videos_grid(videos, path, rescale=False, n_rows=6, fps=8):
         u8 = display_bytes(videos, rescale)
     frames = grid_frames(u8, n_rows, border=127 if rescale else 0)
     save_videos_from_pil([Image.fromarray(fr) for fr in frames], path, fps)
+
+
+def read_frames(video_path):
+    """every frame of the first video stream as an RGB PIL image (util.py:107-121; scripts/pose2vid.py:128 reads the pose
+    video with it)"""
+    av = _av()
+    with av.open(video_path) as container:
+        stream = next(st for st in container.streams if st.type == "video")
+        return [frame.to_image().convert("RGB") for frame in container.decode(stream)]
+
+
+def get_fps(video_path):
+    """average frame rate of the first video stream, as PyAV reports it — a Fraction (util.py:124-129)"""
+    av = _av()
+    with av.open(video_path) as container:
+        return next(st for st in container.streams if st.type == "video").average_rate
+
+
+def seed_everything(seed):
+    """torch (CPU + every GPU), numpy and `random` from one seed (util.py:17-25)"""
+    import random
+    random.seed(seed)
+    np.random.seed(seed % (2 ** 32))
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)

@@ -104,21 +104,9 @@ typedef struct anip_gemm_params {
    * The K projection of anip_ref_attention (to_k of src/models/mutual_self_attention.py:147-165): a 64-key tile of one
    * head is then one contiguous run instead of 2 d-byte pieces at a C-byte stride. */
   int head_dim;
-  /* LayerNorm folded into the GEMM (ln_stats != NULL): A holds the RAW rows x, W the weights multiplied by the norm's gamma
-   * (W'[n][k] = W[n][k] gamma[k], fp16), ln_stats = (mean, rstd) fp32 per row of A (anip_row_stats), ln_colsum[n] =
-   * sum_k W'[n][k] fp32, and `bias` = beta W^T + b.  The kernel applies out = rstd (alpha acc - alpha mean colsum) + bias
-   * to its finished accumulators: nn.LayerNorm -> nn.Linear (src/models/attention.py:331-362, src/models/motion_module.py:
-   * 228-234) without the normalised tensor ever being written or read.  Any epilogue (bias, row-group bias, residual,
-   * GEGLU, transposed / head-major output); plain single-source A, batch 1, no split-K: anip_gemm_supports_ln(p) tells
-   * whether a problem qualifies (the caller otherwise runs anip_layernorm + anip_gemm). */
-  const float* ln_stats; const float* ln_colsum;
 } anip_gemm_params;
 int64_t anip_gemm_workspace_bytes(const anip_gemm_params* p);
 int anip_gemm(const anip_gemm_params* p, void* stream);
-int anip_gemm_supports_ln(const anip_gemm_params* p);
-/* (mean, rstd) fp32 pairs of the rows of x [M][ld] fp16 over C channels (C % 8 == 0): the statistics of nn.LayerNorm(C, eps),
- * two-pass in registers like anip_layernorm — the input of the LayerNorm fold of anip_gemm. */
-int anip_row_stats(const void* x, int64_t ld, float* stats, int64_t M, int C, float eps, void* stream);
 
 /* ---- fused GEGLU feed-forward (the engine's default at C = 320; ANIP_FUSED_FFN=0 selects two anip_gemm calls) -------
  * out[M][C] = residual + b2 + W2 · ((x W1v^T + b1v) * gelu_erf(x W1g^T + b1g)):  diffusers FeedForward("geglu") of
@@ -203,6 +191,28 @@ int anip_temporal_attention(const void* qkv, void* out, int B, int F, int T, int
  *   out      [(b F) T][C] fp16   attention output (token-major, heads concatenated) = input of to_out
  * Built for F = 16, C = 320, heads = 8 (d = 40), T % 8 == 0 — anip_temporal_qkv_attention_supported tells (1 / 0);
  * every other shape stays on anip_layernorm + anip_gemm + anip_temporal_attention.  scale = d^-1/2 of the reference. */
+/* ---- row-stationary projections at C = 320 (csrc/tblock.hip) ---------------------------------------------------
+ * The 64x64 level's K = 320 Linears are bound by memory traffic; these keep a wave's 32 rows in registers through their
+ * normalisation AND their projections.  anip_rowgemm320_supported: C == 320, M % 128 == 0, rows_per_frame % 32 == 0 (or 0).
+ *
+ * anip_ln_qkv_projection — norm1 -> attn1.to_q / to_k / to_v of a spatial (Temporal)BasicTransformerBlock
+ *   (src/models/attention.py:383-401, consumed by src/models/mutual_self_attention.py:147-186) in the three layouts
+ *   anip_ref_attention reads: q [M][C] token-major multiplied by q_alpha, k head-major [heads][M][d], v^T [C][ldvt].
+ *   w_qkv [3C][C] fp16 = rows of to_q, then to_k, then to_v.  Replaces anip_layernorm + three anip_gemm calls.
+ *
+ * anip_groupnorm_scale_shift + anip_affine_linear320 — Transformer3DModel / temporal transformer  norm -> proj_in
+ *   (src/models/transformer_3d.py:128-139, src/models/motion_module.py:185-204): the per-frame GroupNorm statistics are
+ *   finalised into scale_shift [N][C][2] fp32 = (rstd gamma, beta - mean rstd gamma) and applied to the rows on their way
+ *   into the 1x1 convolution: out = (x * scale[frame] + shift[frame]) W^T + bias.  Replaces anip_groupnorm + anip_gemm. */
+int anip_rowgemm320_supported(int64_t M, int C, int64_t rows_per_frame);
+int anip_ln_qkv_projection(const void* x, const float* gamma, const float* beta, float eps, const void* w_qkv, void* q,
+                           float q_alpha, void* k_head_major, void* vt, int64_t ldvt, int64_t M, int C, int heads,
+                           void* stream);
+int anip_groupnorm_scale_shift(const void* x, const float* gamma, const float* beta, float* scale_shift, int N, int64_t HW,
+                               int C, int G, float eps, float* ws, void* stream);
+int anip_affine_linear320(const void* x, const float* scale_shift, int64_t rows_per_frame, const void* w, const float* bias,
+                          void* out, int64_t M, int C, void* stream);
+
 int anip_temporal_qkv_attention_supported(int F, int T, int C, int heads);
 int anip_temporal_qkv_attention(const void* x, const float* gamma, const float* beta_pe, const void* w_packed, void* out,
                                 int B, int F, int T, int C, int heads, float eps, float scale, void* stream);

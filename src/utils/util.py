@@ -1,12 +1,13 @@
-"""replaces /root/reference/src/utils/util.py for the output side of the path: `save_videos_grid`
-and `save_videos_from_pil` (scripts/pose2vid.py:26, scripts/audio2vid.py:27, scripts/vid2vid.py:26).  Any other name
-(`read_frames`, `get_fps`, `crop_face`, the training scripts' host helpers) is served from the reference's own module — the
-next `src/utils/util.py` on the namespace package's path — loaded on first use."""
+"""replaces /root/reference/src/utils/util.py for what the inference scripts import from it (scripts/pose2vid.py:26,
+scripts/audio2vid.py:27, scripts/vid2vid.py:26): `save_videos_grid`, `save_videos_from_pil` (the output side of the path,
+SURVEY.md §8f rank 4), `read_frames`, `get_fps`, `seed_everything` — served by aniportrait_amd.video_io, PyAV imported on first
+use, no cv2 / torchvision / einops.  Any other name (`crop_face`, the training scripts' host helpers) is served from the
+reference's own module — the next `src/utils/util.py` on the namespace package's path — loaded on first use."""
 import importlib.util
 import os
 import sys
 
-from aniportrait_amd.video_io import save_videos_from_pil, save_videos_grid  # noqa: F401
+from aniportrait_amd.video_io import get_fps, read_frames, save_videos_from_pil, save_videos_grid, seed_everything  # noqa: F401
 
 _reference = None
 

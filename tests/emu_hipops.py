@@ -25,6 +25,42 @@ def groupnorm(x1, gamma, beta, groups, eps, silu, x2=None, frames_per_stat=1):
     return y.to(F16).contiguous()
 
 
+def rowgemm320_supported(M, C, rows_per_frame=0):
+    return C == 320 and M > 0 and M % 128 == 0 and (rows_per_frame == 0 or rows_per_frame % 32 == 0)
+
+
+def groupnorm_scale_shift(x, gamma, beta, groups, eps):
+    N, HW, C = x.shape
+    xs = x.float().reshape(N, HW, groups, C // groups)
+    mean = xs.mean(dim=(1, 3))
+    var = xs.var(dim=(1, 3), unbiased=False)
+    rstd = (var + eps).rsqrt()
+    sc = rstd.repeat_interleave(C // groups, dim=1) * gamma.float()[None]
+    sh = beta.float()[None] - mean.repeat_interleave(C // groups, dim=1) * sc
+    return torch.stack([sc, sh], dim=-1).contiguous()
+
+
+def affine_linear320(x, scale_shift, rows_per_frame, W, bias=None):
+    M, C = x.shape
+    idx = torch.arange(M) // rows_per_frame
+    xn = (x.float() * scale_shift[idx, :, 0] + scale_shift[idx, :, 1]).to(F16)
+    y = xn.float() @ W.float().t()
+    if bias is not None:
+        y = y + bias.float()
+    return y.to(F16)
+
+
+def ln_qkv_projection(x, gamma, beta, w_qkv, heads, q_alpha, eps=1e-5):
+    M, C = x.shape
+    d = C // heads
+    nh = layernorm(x, gamma, beta, eps).float()
+    y = nh @ w_qkv.float().t()
+    q = (q_alpha * y[:, :C]).to(F16)
+    k = y[:, C:2 * C].to(F16).reshape(M, heads, d).permute(1, 0, 2).contiguous()
+    vt = y[:, 2 * C:].to(F16).t().contiguous()
+    return q, k, vt
+
+
 def layernorm(x, gamma, beta, eps=1e-5, pe=None, rows_per_frame=0, frames=0):
     y = F.layer_norm(x.float(), (x.shape[-1],), gamma.float(), beta.float(), eps)
     if pe is not None:
@@ -41,7 +77,7 @@ def _geglu_unpack(y):
 
 
 def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None, act=0, out_f32=False,
-         alpha=1.0, out=None, conv=None, batch=1, ldo=None, ldr=None, trans_out=False, head_dim=0, ln=None):
+         alpha=1.0, out=None, conv=None, batch=1, ldo=None, ldr=None, trans_out=False, head_dim=0):
     assert A.dtype == F16 and W.dtype == F16
     if A.dim() == 3 or W.dim() == 3:
         y = alpha * torch.matmul(A.float(), W.float().transpose(-1, -2))
@@ -67,9 +103,6 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
     else:
         a = A.float() if A2 is None else torch.cat([A.float(), A2.float()], dim=1)
         y = alpha * (a @ W.float().t())
-        if ln is not None:      # LayerNorm fold: rstd (alpha acc - mean colsum) with colsum (and bias) already carrying alpha
-            stats, colsum = ln
-            y = stats[:, 1:2] * (y - stats[:, 0:1] * colsum.float()[None, :])
     M, N = y.shape
     if bias is not None:
         y = y + bias.float()
@@ -90,17 +123,6 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
         out.copy_(y.reshape(out.shape))
         return out
     return y
-
-
-def row_stats(x, eps=1e-5):
-    xf = x.float()
-    mean = xf.mean(dim=1)
-    var = (xf - mean[:, None]).pow(2).mean(dim=1)
-    return torch.stack([mean, torch.rsqrt(var + eps)], dim=1).contiguous()
-
-
-def gemm_supports_ln(M, N, K, act=0, trans_out=False, head_dim=0, lda=None, ldw=None):
-    return True       # the emulation has one GEMM: every shape takes the folded form (the engine's other branch is the old path)
 
 
 def ffn_geglu(x, w1p, b1p, w2, b2, residual=None):
@@ -283,7 +305,7 @@ def f16_to_u8(src, scale=1.0, shift=0.0):
     return ((src.float() * scale + shift).clamp(0, 1).to(F16).float() * 255.0).to(torch.uint8)
 
 
-_EMULATED = ("groupnorm", "layernorm", "gemm", "row_stats", "gemm_supports_ln", "ffn_geglu", "ffn_geglu_ln", "conv3x3", "conv_small", "conv_direct", "batchnorm", "ref_attention",
+_EMULATED = ("groupnorm", "layernorm", "rowgemm320_supported", "groupnorm_scale_shift", "affine_linear320", "ln_qkv_projection", "gemm", "ffn_geglu", "ffn_geglu_ln", "conv3x3", "conv_small", "conv_direct", "batchnorm", "ref_attention",
              "temporal_attention", "temporal_qkv_attention", "temporal_qkv_attention_supported", "softmax_rows", "linear_small", "add", "window_accumulate", "cfg_ddim_step",
              "ncfhw_to_nhwc", "nhwc_to_ncfhw", "u8_to_f16", "f16_to_u8")
 

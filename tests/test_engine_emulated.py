@@ -68,34 +68,6 @@ def test_unets_and_vae_engine_match_reference(emu, gold):
 
 
 @torch.no_grad()
-def test_layernorm_fold_branches_of_the_engine_match_reference(emu, gold, monkeypatch):
-    """ANIP_LN_FOLD=1 (off by default: a measured net loss on MI355X): nn.LayerNorm folded into the q / k / v^T,
-    temporal qkv and GEGLU projections — gamma in the weights, beta W^T in the bias, mean / rstd applied to the accumulators
-    (anip_gemm_params.ln_stats).  The engine's fold branches and hipops.fold_layernorm stay checked against the same goldens."""
-    from aniportrait_amd import engine
-    from golden_inputs import unet_case
-    from src.models.mutual_self_attention import ReferenceAttentionControl
-    monkeypatch.setattr(engine, "_LN_FOLD", True)
-    monkeypatch.setattr(engine, "_ln_ok_cache", {})
-    m, _ = build_hip_models(True, keys=("denoising_unet", "reference_unet"), device="cpu")
-    c = unet_case(True)
-    wr = ReferenceAttentionControl(m["reference_unet"], do_classifier_free_guidance=True, mode="write", batch_size=1,
-                                   fusion_blocks="full")
-    rd = ReferenceAttentionControl(m["denoising_unet"], do_classifier_free_guidance=True, mode="read", batch_size=1,
-                                   fusion_blocks="full")
-    m["reference_unet"](c["ref_lat"].repeat(2, 1, 1, 1), torch.zeros((), dtype=torch.long),
-                        encoder_hidden_states=c["ehs"], return_dict=False)
-    rd.update(wr)
-    for p, rb in m["denoising_unet"]._ref_blocks.items():
-        assert rel_err(rb.node.bank[0].float(), gold["bank/" + p].float()) < TOL, p
-    pose = [gold[f"pose_fea/{i}"] for i in range(5)]
-    out = m["denoising_unet"](c["lat"], torch.tensor(c["t"]), encoder_hidden_states=c["ehs"], pose_cond_fea=pose)
-    assert rel_err(out.sample, gold["unet_out"]) < TOL
-    assert any(v for v in engine._ln_ok_cache.values()), "no GEMM of the walk took the fold: the branch was not exercised"
-    rd.clear(); wr.clear()
-
-
-@torch.no_grad()
 @pytest.mark.parametrize("case", ["long_L4", "long_L10_ctx8"])
 def test_pipeline_host_logic_matches_reference_video(emu, case):
     from aniportrait_amd import configs as C
@@ -146,6 +118,45 @@ def test_inference_v1_groupnorm_variant_engine_matches_reference(emu):
     gold = load_golden("small_models_v1.pt")
     assert rel_err(out.sample, gold["unet_out_v1"]) < TOL
     assert rel_err(out.sample, gold["unet_out_v1_if_inflated"]) > 1e-2
+
+
+def _v1_models(device):
+    """the product's modules under configs/inference/inference_v1.yaml (UNet3D variant), name-hash weights as the golden's"""
+    from aniportrait_amd import configs as C
+    from aniportrait_amd.unet import UNet3DConditionModel
+    from util import oracle_state_dicts
+    m, _ = build_hip_models(True, keys=("reference_unet", "vae", "pose_guider"), device=device)
+    net = UNet3DConditionModel(**C.unet3d_kwargs_v1(True))
+    sd = oracle_state_dicts(True, keys=["denoising_unet"])["denoising_unet"]
+    missing, unexpected = net.load_state_dict({k: v for k, v in sd.items() if not k.startswith("mid_block.motion_modules")},
+                                              strict=False)
+    assert not unexpected and all(x.endswith(".pe") for x in missing)
+    m["denoising_unet"] = net.to(device, torch.float16)
+    return m
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("case", ["long_L4", "long_L10_ctx8"])
+def test_inference_v1_pipeline_matches_reference_video(emu, case):
+    """configs/inference/inference_v1.yaml END TO END: its UNet3D variant and its scheduler (epsilon prediction, leading spacing,
+    no zero-SNR) through the pipeline's fused CFG + DDIM step, against the video the reference's own pipeline produced with the
+    same configuration (oracle/make_golden.py --v1-pipeline)"""
+    from aniportrait_amd import configs as C
+    from aniportrait_amd.scheduling_ddim import DDIMScheduler
+    from golden_inputs import pipe_inputs
+    from src.pipelines.pipeline_pose2vid_long import Pose2VideoPipeline
+    gold = load_golden("small_pipeline_v1.pt")
+    m = _v1_models("cpu")
+    i = pipe_inputs(case)
+    pipe = Pose2VideoPipeline(vae=m["vae"], image_encoder=small_clip_encoder("cpu"), reference_unet=m["reference_unet"],
+                              denoising_unet=m["denoising_unet"], pose_guider=m["pose_guider"],
+                              scheduler=DDIMScheduler(**C.DDIM_V1))
+    pipe.set_progress_bar_config(disable=True)
+    vid = pipe(i["ref_image"], list(i["poses"]), i["ref_pose"], i["W"], i["H"], i["L"], i["steps"], i["cfg"],
+               latents=i["latents"], **i["kw"]).videos
+    assert psnr(vid, gold[case + "/video_f16"].float()) >= 40.0
+    # and it is not the v2 schedule in disguise
+    assert psnr(load_golden("small_pipeline.pt")[case + "/video_f16"].float(), gold[case + "/video_f16"].float()) < 30.0
 
 
 @torch.no_grad()
@@ -200,3 +211,44 @@ def test_fused_temporal_branch_of_the_motion_module_matches_the_three_launch_bra
     h = h + (u[..., :4 * C] * Fn.gelu(u[..., 4 * C:])) @ sd[bp + ".ff.net.2.weight"].t() + sd[bp + ".ff.net.2.bias"]
     ref = (h @ sd[p + ".proj_out.weight"].t() + sd[p + ".proj_out.bias"] + xs).reshape(b * f, H, W, C)
     assert rel_err(outs[True], ref) < TOL
+
+
+@torch.no_grad()
+def test_row_stationary_branches_of_the_spatial_transformer_match_the_separate_launches(emu, monkeypatch):
+    """C = 320, M % 128 == 0 (the 64x64 level): engine.spatial_transformer through anip_groupnorm_scale_shift +
+    anip_affine_linear320 (GroupNorm inside proj_in) and anip_ln_qkv_projection (norm1 inside the q | k | v^T projections),
+    against the groupnorm -> gemm / layernorm -> three GEMMs branches — plain, write and read mode"""
+    from aniportrait_amd import engine
+    g = torch.Generator().manual_seed(7)
+    C, heads, N, H, W = 320, 8, 2, 8, 16
+    r = lambda *s, scale=1.0: (torch.randn(s, generator=g) * scale).half().float()
+    p = "st"
+    bp = p + ".transformer_blocks.0"
+    sd = {p + ".norm.weight": 1 + 0.1 * r(C), p + ".norm.bias": 0.1 * r(C),
+          p + ".proj_in.weight": r(C, C, 1, 1, scale=C ** -0.5), p + ".proj_in.bias": 0.1 * r(C),
+          p + ".proj_out.weight": r(C, C, 1, 1, scale=C ** -0.5), p + ".proj_out.bias": 0.1 * r(C),
+          bp + ".norm1.weight": 1 + 0.1 * r(C), bp + ".norm1.bias": 0.1 * r(C),
+          bp + ".norm3.weight": 1 + 0.1 * r(C), bp + ".norm3.bias": 0.1 * r(C),
+          bp + ".attn1.to_out.0.weight": r(C, C, scale=C ** -0.5), bp + ".attn1.to_out.0.bias": 0.1 * r(C),
+          bp + ".ff.net.0.proj.weight": r(8 * C, C, scale=C ** -0.5), bp + ".ff.net.0.proj.bias": 0.1 * r(8 * C),
+          bp + ".ff.net.2.weight": r(C, 4 * C, scale=(4 * C) ** -0.5), bp + ".ff.net.2.bias": 0.1 * r(C)}
+    for n in ("to_q", "to_k", "to_v"):
+        sd[bp + f".attn1.{n}.weight"] = r(C, C, scale=C ** -0.5)
+    x = (r(N, H, W, C) + 0.5).half()
+    attn2 = 0.1 * r(N, C)
+    bank = r(N, H * W, C).half()
+    for mode in ("plain", "read", "write"):
+        outs = {}
+        for fused in (True, False):
+            monkeypatch.setattr(engine, "_FUSED_ROWS", fused)
+            ref = engine.RefState()
+            ref.mode = mode
+            ridx = None
+            if mode == "read":
+                ref.bank = bank
+                ridx = (torch.tensor([-1, 1], dtype=torch.int32), 1)
+            out = engine.spatial_transformer(engine.PackedNet(sd, "cpu"), p, x, heads, attn2, 1, ref=ref, ref_index=ridx)
+            outs[fused] = (out.float(), None if ref.written is None else ref.written.float())
+        assert rel_err(outs[True][0], outs[False][0]) < 3e-3, mode
+        if mode == "write":
+            assert rel_err(outs[True][1], outs[False][1]) < 3e-3

@@ -291,3 +291,35 @@ def test_inference_v1_groupnorm_variant_on_the_gpu():
     e = rel_err(out.float().cpu(), gold["unet_out_v1"])
     print(f"inference_v1 UNet3D (cross-frame GroupNorm) vs reference golden: {e:.2e} of max")
     assert e < 6e-3 and rel_err(out.float().cpu(), gold["unet_out_v1_if_inflated"]) > 1e-2
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("case", ["long_L4", "long_L10_ctx8"])
+def test_inference_v1_pipeline_on_the_gpu(case):
+    """configs/inference/inference_v1.yaml END TO END on the HIP kernels: its UNet3D variant (cross-frame GroupNorm, no mid-block
+    motion module, 24-frame pe table) and its scheduler (:18-23 — epsilon prediction, leading spacing, no zero-SNR rescale)
+    through the fused CFG + DDIM step, against the video the reference's own pipeline produced under the same configuration
+    (oracle/make_golden.py --v1-pipeline)"""
+    from aniportrait_amd import configs as C
+    from aniportrait_amd.scheduling_ddim import DDIMScheduler
+    from aniportrait_amd.unet import UNet3DConditionModel
+    from golden_inputs import pipe_inputs
+    from src.pipelines.pipeline_pose2vid_long import Pose2VideoPipeline
+    from util import load_golden, oracle_state_dicts, psnr, small_clip_encoder
+    gold = load_golden("small_pipeline_v1.pt")
+    m, _ = build_hip_models(True, keys=("reference_unet", "vae", "pose_guider"))
+    net = UNet3DConditionModel(**C.unet3d_kwargs_v1(True))
+    sd = oracle_state_dicts(True, keys=["denoising_unet"])["denoising_unet"]
+    missing, unexpected = net.load_state_dict({k: v for k, v in sd.items() if not k.startswith("mid_block.motion_modules")},
+                                              strict=False)
+    assert not unexpected and all(x.endswith(".pe") for x in missing)
+    i = pipe_inputs(case)
+    pipe = Pose2VideoPipeline(vae=m["vae"], image_encoder=small_clip_encoder(), reference_unet=m["reference_unet"],
+                              denoising_unet=net.to("cuda", torch.float16), pose_guider=m["pose_guider"],
+                              scheduler=DDIMScheduler(**C.DDIM_V1))
+    pipe.set_progress_bar_config(disable=True)
+    vid = pipe(i["ref_image"], list(i["poses"]), i["ref_pose"], i["W"], i["H"], i["L"], i["steps"], i["cfg"],
+               latents=i["latents"], **i["kw"]).videos
+    p = psnr(vid, gold[case + "/video_f16"].float())
+    print(f"inference_v1 pipeline {case}: PSNR vs the reference's v1 run = {p:.2f} dB")
+    assert p >= 40.0

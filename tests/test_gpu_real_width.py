@@ -10,8 +10,10 @@ the north star's criterion: PSNR >= 40 dB on the decoded frames for identical we
                       2 of the 16 frames; round 2's first GPU run did 2 steps x 16 frames: 46.4 dB, oracle 425 s)
   reference fixtures  tests/golden/real_pipeline_<case>.pt — outputs of the REFERENCE's own pipeline run on PyTorch-CPU fp32 in
                       the build container (oracle/make_golden_real_pipeline.py): C2 geometry at 4 DDIM steps, all 16 frames;
-                      C5 geometry (768x768, 96x96 latents) at 1 step; L=40 at real width (4 windows per step incl. the
-                      wrap-around one, shifting with the step).  Only compared here — no CPU oracle run on the GPU box.
+                      C5 geometry (768x768, 96x96 latents) at 1 and 4 steps; C2 in full (25 steps); L=40 at real width (4 windows
+                      per step incl. the wrap-around one — the same windows at every step: the reference passes step 0 to its
+                      context scheduler); C4 at its own geometry (512x512, L=150: 13 windows) at 1 step.  Only compared here —
+                      no CPU oracle run on the GPU box.
   graph reuse         clip A, a different clip B (other image / poses / latents / resolution), clip A again through the
                       SAME pipeline object with the captured hipGraph active: every clip matches the oracle and A is
                       bit-identical before and after B (in-place bank / attn2 refresh, runner cache)
@@ -196,6 +198,27 @@ def test_l40_wraparound_windows_vs_reference_fixture(real_pipe):
     p, worst, lat_db = _report("L40", vid, lats, gold, i)
     assert vid.shape == (1, 3, 40, 128, 128)
     assert p >= PSNR_BAR and worst >= PSNR_BAR and min(lat_db) >= 40.0
+
+
+@torch.no_grad()
+def test_c4_long_clip_150_frames_one_step_vs_reference_fixture(real_pipe):
+    """BASELINE configs[3] at its OWN geometry — 512x512, L=150: 13 overlapping 16-frame context windows per step, the last one
+    wrapping around the clip end ([144..149, 0..9]), window sums and counters merged over 150 frames
+    (src/pipelines/pipeline_pose2vid_long.py:487-555) — at 1 DDIM step against the reference's own pipeline on PyTorch-CPU fp32
+    (oracle/make_golden_real_pipeline.py c4_1step): the latents of ALL 150 frames after the step, and six decoded frames out of
+    plain, overlapping and wrap-around windows"""
+    pipe, _ = real_pipe
+    vid, lats, gold, i = _fixture_case(pipe, "c4_1step")
+    p, worst, lat_db = _report("C4 1 step", vid, lats, gold, i)
+    assert vid.shape == (1, 3, 150, 512, 512) and len(lats) == 1 and tuple(lats[0].shape) == (1, 4, 150, 64, 64)
+    assert p >= PSNR_BAR and worst >= PSNR_BAR and min(lat_db) >= 40.0
+    # per-frame latent SNR: every frame of the clip (each lies in one or two windows), not only the decoded ones
+    ref = gold["latents_f16"][0].float()
+    err = ((lats[0].double() - ref.double()) ** 2).mean(dim=(0, 1, 3, 4))
+    sig = ref.double().pow(2).mean(dim=(0, 1, 3, 4))
+    snr = 10 * torch.log10(sig / err.clamp_min(1e-30))
+    print(f"C4 latent SNR per frame: min {float(snr.min()):.1f} dB (frame {int(snr.argmin())}), median {float(snr.median()):.1f} dB")
+    assert float(snr.min()) >= 40.0
 
 
 @pytest.mark.slow

@@ -251,65 +251,6 @@ def test_softmax_rows():
     close(ops.softmax_rows(s), torch.softmax(s, -1), "softmax rows 100", rtol=2e-3, arms=1e-2)
 
 
-@pytest.mark.parametrize("case", ["bias", "residual", "head_major", "trans", "geglu", "rowbias", "ragged", "alpha", "wide1280"])
-def test_gemm_layernorm_fold(case):
-    """anip_gemm_params.ln_stats: LayerNorm folded into the consuming GEMM — raw rows in, gamma inside the weights, the
-    rank-one mean correction and rstd applied to the accumulators — against LayerNorm -> Linear in fp32, in every
-    epilogue form the engine uses it with (attention.py:331-362, motion_module.py:228-234)"""
-    ops = _ops()
-    M, K, N, kw, act = 8192, 320, 320, {}, 0
-    if case == "geglu":
-        K, N, act = 640, 5120, 1
-    if case == "rowbias":
-        N = 960
-    if case == "ragged":
-        M = 33003
-    if case == "wide1280":
-        M, K, N = 2048, 1280, 3840
-    x = (rnd(M, K, seed=400, scale=1.5).float() + 0.7 * rnd(M, 1, seed=401).float()).half().to(DEV)   # rows with their own means
-    W = rnd(N, K, seed=402, scale=K ** -0.5).to(DEV)
-    b = rnd(N, seed=403).float().to(DEV)
-    gamma = (1.0 + 0.3 * rnd(K, seed=404).float()).to(DEV)
-    beta = (0.2 * rnd(K, seed=405).float()).to(DEV)
-    alpha = 0.228 if case == "alpha" else 1.0
-    ref = alpha * (torch.nn.functional.layer_norm(x.float(), (K,), gamma, beta, 1e-5) @ W.float().t() + b)
-    if case == "residual":
-        kw["residual"] = rnd(M, N, seed=406).to(DEV)
-        ref = ref + kw["residual"].float()
-    if case == "rowbias":
-        kw["rowbias"], kw["rows_per_group"] = rnd(M // 256, N, seed=407).float().to(DEV), 256
-        ref = ref + kw["rowbias"].repeat_interleave(256, dim=0)
-    if case == "head_major":
-        kw["head_dim"] = 40
-    if case == "trans":
-        kw["trans_out"] = True
-    if act == 1:
-        ref = ref[:, : N // 2] * torch.nn.functional.gelu(ref[:, N // 2:])
-    assert ops.gemm_supports_ln(M, N, K, act=act, trans_out=case == "trans", head_dim=kw.get("head_dim", 0))
-    Wf, colsum, bf = ops.fold_layernorm(W, b, gamma, beta, alpha=alpha, geglu=act == 1)
-    got = ops.gemm(x, Wf, bf, act=act, alpha=alpha, ln=(ops.row_stats(x, 1e-5), colsum), **kw)
-    if case == "head_major":
-        got = got.permute(1, 0, 2).reshape(M, N)
-    if case == "trans":
-        got = got.t()
-    close(got, ref, f"gemm LN fold {case}", rtol=6e-3, arms=6e-3)
-    # and no worse than the two-kernel form it replaces
-    if case in ("bias", "residual"):
-        two = ops.gemm(ops.layernorm(x, gamma, beta, 1e-5), W, b, **kw)
-        e_fold = float((got.float() - ref).pow(2).mean().sqrt())
-        e_two = float((two.float() - ref).pow(2).mean().sqrt())
-        assert e_fold <= 1.5 * e_two + 1e-4, (e_fold, e_two)
-
-
-def test_gemm_layernorm_fold_not_supported_shapes():
-    ops = _ops()
-    assert not ops.gemm_supports_ln(100, 320, 320)        # the small-problem kernel does not carry the fold
-    assert ops.gemm_supports_ln(2048, 1280, 1280)
-
-
-# ------------------------------------------------------------------------------------------------
-# attention
-# ------------------------------------------------------------------------------------------------
 def _attn_ref(q, k, v, scale):
     s = torch.einsum("hqd,hkd->hqk", q, k) * scale
     return torch.einsum("hqk,hkd->hqd", torch.softmax(s, -1), v)
@@ -584,18 +525,87 @@ def test_temporal_qkv_attention_fused(B, T, wscale, with_pe):
     bpe = (beta[None, :] + pe).contiguous().to(DEV)
     wp = ops.pack_temporal_qkv(wq.to(DEV), wk.to(DEV), wv.to(DEV))
     out = ops.temporal_qkv_attention(xd, gd, bpe, wp, B, Fr, T, heads)
-    close(out, ref, f"temporal_qkv_attention B{B} T{T} wscale{wscale}", rtol=4e-3, arms=4e-3)
+    tol = 4e-3 if wscale <= 1.0 else 8e-3      # peaky rows: a flipped fp16 rounding of one q / k element moves a probability by ~1 %
+    close(out, ref, f"temporal_qkv_attention B{B} T{T} wscale{wscale}", rtol=tol, arms=tol)
     nh = ops.layernorm(xd, gd, beta.to(DEV), pe=pe.contiguous().to(DEV), rows_per_frame=T, frames=Fr)
     qkv = ops.gemm(nh, torch.cat([wq, wk, wv]).to(DEV))
     three = ops.temporal_attention(qkv, B, Fr, T, heads, d)
-    close(out, three, f"temporal_qkv_attention vs three launches B{B} T{T}", rtol=4e-3, arms=2e-3)
+    close(out, three, f"temporal_qkv_attention vs three launches B{B} T{T}", rtol=tol, arms=tol)
     assert torch.equal(out, ops.temporal_qkv_attention(xd, gd, bpe, wp, B, Fr, T, heads)), "not deterministic"
+
+
+@pytest.mark.parametrize("M", [128, 4096, 131072])
+def test_ln_qkv_projection_fused(M):
+    """csrc/tblock.hip rowgemm320_kernel<0>: norm1 -> to_q (x alpha, token-major) | to_k (head-major) | to_v (transposed) in one
+    launch, against fp32 and against anip_layernorm + the three GEMMs it replaces; then through anip_ref_attention"""
+    ops = _ops()
+    C, heads, d = 320, 8, 40
+    assert ops.rowgemm320_supported(M, C) and not ops.rowgemm320_supported(M + 64, C) and not ops.rowgemm320_supported(M, 640)
+    x = rnd(M, C, seed=150, scale=1.6, shift=-0.2)
+    gamma = 1.0 + 0.2 * rnd(C, seed=151).float()
+    beta = 0.1 * rnd(C, seed=152).float()
+    wq, wk, wv = (rnd(C, C, seed=153 + i, scale=C ** -0.5) for i in range(3))
+    qa = ops.attn_q_alpha(d)
+    xd, gd, bd = x.to(DEV), gamma.to(DEV), beta.to(DEV)
+    q, k, vt = ops.ln_qkv_projection(xd, gd, bd, torch.cat([wq, wk, wv]).to(DEV), heads, qa)
+    assert tuple(q.shape) == (M, C) and tuple(k.shape) == (heads, M, d) and tuple(vt.shape) == (C, M)
+    nh = ops.layernorm(xd, gd, bd)
+    q3 = ops.gemm(nh, wq.to(DEV), alpha=qa)
+    k3 = ops.gemm(nh, wk.to(DEV), head_dim=d)
+    vt3 = ops.gemm(nh, wv.to(DEV), trans_out=True)
+    close(q, q3, f"ln_qkv q vs three launches M{M}", rtol=2e-3, arms=1e-3)
+    close(k, k3, f"ln_qkv k vs three launches M{M}", rtol=2e-3, arms=1e-3)
+    close(vt, vt3, f"ln_qkv vt vs three launches M{M}", rtol=2e-3, arms=1e-3)
+    if M <= 4096:
+        n = F.layer_norm(x.float(), (C,), gamma, beta, 1e-5).half().float()
+        close(q, qa * (n @ wq.float().t()), f"ln_qkv q M{M}")
+        close(k, (n @ wk.float().t()).reshape(M, heads, d).permute(1, 0, 2), f"ln_qkv k M{M}")
+        close(vt, (n @ wv.float().t()).t(), f"ln_qkv vt M{M}")
+    assert all(torch.equal(a, b) for a, b in zip((q, k, vt), ops.ln_qkv_projection(xd, gd, bd, torch.cat([wq, wk, wv]).to(DEV), heads, qa)))
+    if M == 4096:   # the layouts are the ones the attention kernel reads: one frame of 4096 tokens
+        a = ops.ref_attention(q, C, k, d, vt, M, 1, M, heads, d, k_head_stride=M * d, q_log2_scaled=True)
+        a3 = ops.ref_attention(q3, C, k3, d, vt3, M, 1, M, heads, d, k_head_stride=M * d, q_log2_scaled=True)
+        close(a, a3, "ref_attention on fused projections", rtol=4e-3, arms=4e-3)
+
+
+@pytest.mark.parametrize("N,HW", [(2, 64), (3, 1024), (32, 4096)])
+def test_groupnorm_affine_linear_fused(N, HW):
+    """anip_groupnorm_scale_shift + anip_affine_linear320 (rowgemm320_kernel<1>): GroupNorm(32, eps 1e-6) -> proj_in without the
+    normalised tensor, against fp32 and against anip_groupnorm + anip_gemm"""
+    ops = _ops()
+    C, G = 320, 32
+    M = N * HW
+    x = rnd(N, HW, C, seed=160, scale=1.3)
+    x = x + (torch.arange(C) % 7).half() * 0.5 + torch.arange(N).half()[:, None, None] * 0.25     # group means away from zero, per frame
+    gamma = 1.0 + 0.2 * rnd(C, seed=161).float()
+    beta = 0.1 * rnd(C, seed=162).float()
+    W = rnd(C, C, seed=163, scale=C ** -0.5)
+    bias = rnd(C, seed=164).float()
+    xd, gd, bd = x.to(DEV), gamma.to(DEV), beta.to(DEV)
+    assert ops.rowgemm320_supported(M, C, HW)
+    sst = ops.groupnorm_scale_shift(xd, gd, bd, G, 1e-6)
+    xs = x.float().reshape(N, HW, G, C // G)
+    mean, var = xs.mean(dim=(1, 3)), xs.var(dim=(1, 3), unbiased=False)
+    sc = (var + 1e-6).rsqrt().repeat_interleave(C // G, 1) * gamma
+    sh = beta - mean.repeat_interleave(C // G, 1) * sc
+    close(sst[..., 0], sc, f"gn scale N{N} HW{HW}", rtol=1e-4, arms=1e-5)
+    close(sst[..., 1], sh, f"gn shift N{N} HW{HW}", rtol=1e-4, arms=1e-4)
+    out = ops.affine_linear320(xd.reshape(M, C), sst, HW, W.to(DEV), bias.to(DEV))
+    two = ops.gemm(ops.groupnorm(xd, gd, bd, G, 1e-6, False).reshape(M, C), W.to(DEV), bias.to(DEV))
+    close(out, two, f"affine_linear320 vs groupnorm + gemm N{N} HW{HW}", rtol=2e-3, arms=1e-3)
+    if M <= 4096:
+        xn = F.group_norm(x.float().permute(0, 2, 1), G, gamma, beta, 1e-6).permute(0, 2, 1).reshape(M, C).half().float()
+        close(out, xn @ W.float().t() + bias, f"affine_linear320 N{N} HW{HW}")
+    assert torch.equal(out, ops.affine_linear320(xd.reshape(M, C), sst, HW, W.to(DEV), bias.to(DEV)))
+    nob = ops.affine_linear320(xd.reshape(M, C), sst, HW, W.to(DEV), None)
+    close(nob.float() + bias.to(DEV), out, "affine_linear320 without bias", rtol=2e-3, arms=2e-3)
 
 
 # ------------------------------------------------------------------------------------------------
 # small / elementwise
 # ------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,N,K,silu", [(2, 320, 1280, True), (1, 7, 64, False), (2, 1280, 320, False), (16, 33, 768, True)])
+@pytest.mark.parametrize("M,N,K,silu", [(2, 320, 1280, True), (1, 7, 64, False), (2, 1280, 320, False), (16, 33, 768, True),
+                                        (16, 1280, 1280, True), (13, 320, 1280, False)])   # M * K floats beyond one 64-KB LDS stage
 def test_linear_small(M, N, K, silu):
     ops = _ops()
     x = rnd(M, K, seed=90).float().to(DEV)

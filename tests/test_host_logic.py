@@ -60,7 +60,34 @@ def test_ddim_scheduler_matches_oracle():
         assert torch.allclose(fused, want, atol=1e-6)
     assert s.scale_model_input(x, 5) is x
     with pytest.raises(NotImplementedError):
-        DDIMScheduler(**dict(C.DDIM_V2, prediction_type="epsilon")).coefficients(999)
+        DDIMScheduler(**dict(C.DDIM_V2, clip_sample=True)).coefficients(999)
+    eps0 = DDIMScheduler(**dict(C.DDIM_V2, prediction_type="epsilon"))
+    eps0.set_timesteps(25)
+    with pytest.raises(ValueError):            # epsilon prediction at alpha_bar = 0 divides by zero: zero-SNR needs v-prediction
+        eps0.coefficients(999)
+
+
+def test_ddim_scheduler_inference_v1_form():
+    """configs/inference/inference_v1.yaml:18-23 — epsilon prediction, leading spacing with steps_offset 1, no zero-SNR rescale:
+    timesteps as the reference's scheduler produced them (golden), and the fused kernel's four-scalar form reproduces step()
+    for epsilon and sample prediction"""
+    from aniportrait_amd import configs as C
+    from aniportrait_amd.scheduling_ddim import DDIMScheduler
+    from util import load_golden
+    s = DDIMScheduler(**C.DDIM_V1)
+    assert s.config.prediction_type == "epsilon" and s.config.timestep_spacing == "leading" and not s.config.rescale_betas_zero_snr
+    s.set_timesteps(3)
+    assert s.timesteps.tolist() == load_golden("small_pipeline_v1.pt")["timesteps_3"].tolist() == [667, 334, 1]
+    g = torch.Generator().manual_seed(1)
+    x, m = torch.randn((1, 4, 3, 8, 8), generator=g), torch.randn((1, 4, 3, 8, 8), generator=g)
+    for kind in ("epsilon", "sample", "v_prediction"):
+        s = DDIMScheduler(**dict(C.DDIM_V1, prediction_type=kind))
+        s.set_timesteps(25)
+        for t in s.timesteps.tolist()[::6] + [int(s.timesteps[-1])]:
+            want = s.step(m, t, x).prev_sample
+            sa, sb, sap, sbp = s.coefficients(t)
+            fused = sap * (sa * x - sb * m) + sbp * (sa * m + sb * x)   # what anip_cfg_ddim_step computes
+            assert torch.allclose(fused, want, atol=2e-5, rtol=1e-5), (kind, t, float((fused - want).abs().max()))
 
 
 def test_image_processor_matches_oracle():

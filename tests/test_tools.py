@@ -78,3 +78,18 @@ def test_pmc_summarize_knows_every_kernel_of_the_library():
 def test_gpu_session_script_parses():
     for script in ("tools/gpu_round4.sh",):
         subprocess.run(["bash", "-n", os.path.join(REPO, script)], check=True)
+
+
+def test_bench_cpu_baseline_leg_at_toy_sizes():
+    """bench.py's cpu_baseline leg (the oracle timed part by part at the headline geometry and extrapolated linearly; the
+    earlier 256x256 sample as a second field) — the same code at toy sizes: every part is timed, the extrapolation is the
+    stated linear form, and the result carries the fields the driver's JSON line documents"""
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    r = bench.cpu_baseline(size=64, frames=2, c1=(64, 2, 1))
+    assert r["kind"] == "port" and r["extrapolated"] is True and r["unit"] == "frames/s" and r["cores"] >= 1
+    assert r["ddim_steps_timed"] == 2 and r["step_seconds"] > 0 and r["vae_frame_seconds"] > 0 and r["fixed_seconds"] >= 0
+    t_clip = r["fixed_seconds"] + 25 * r["step_seconds"] + 2 * r["vae_frame_seconds"]
+    assert abs(r["value"] - 2 / t_clip) < 1e-9
+    assert "c1_sample" in r and r["c1_sample"]["seconds"] > 0 and "extrapolated" in r["sample"]

@@ -96,3 +96,26 @@ def test_gif_file_and_unsupported_suffix(tmp_path):
     except ImportError:
         with pytest.raises(ImportError, match="PyAV"):
             video_io.save_videos_grid(v, str(tmp_path / "clip.mp4"))
+
+
+def test_script_import_block_resolves_without_the_reference_util(tmp_path):
+    """`from src.utils.util import get_fps, read_frames, save_videos_grid` (scripts/pose2vid.py:26) and `seed_everything`
+    come from this repository: no cv2 / torchvision / einops import, PyAV only when a video is opened"""
+    import random
+    import sys
+
+    from src.utils import util as shim
+    for name in ("get_fps", "read_frames", "save_videos_grid", "save_videos_from_pil", "seed_everything"):
+        assert getattr(shim, name) is getattr(video_io, name)
+    assert "src.utils._reference_util" not in sys.modules or shim._reference is not None    # nothing forced the fall-through
+    shim.seed_everything(123)
+    a = (random.random(), float(np.random.rand()), float(torch.rand(())))
+    shim.seed_everything(123)
+    assert a == (random.random(), float(np.random.rand()), float(torch.rand(())))
+    try:
+        import av  # noqa: F401
+    except ImportError:
+        with pytest.raises(ImportError, match="PyAV"):
+            shim.read_frames(str(tmp_path / "pose.mp4"))
+        with pytest.raises(ImportError, match="PyAV"):
+            shim.get_fps(str(tmp_path / "pose.mp4"))

@@ -61,8 +61,22 @@ def main():
                      ("ffn_geglu_ln", lambda: ops.ffn_geglu_ln(x, gamma, beta, w1p, b1p, W2, b2, x))):
         w, c = both(fn)
         print(json.dumps({"case": name, "us": w, "us_cold": c, "tflops": round(fflops / w * 1e-6, 1)}), flush=True)
-    if hasattr(ops, "ln_qkv_projection"):
-        pass
+    # norm1 -> q | k | v^T of the spatial block
+    qa = ops.attn_q_alpha(d)
+
+    def three_proj():
+        nh = ops.layernorm(x, gamma, beta)
+        return ops.gemm(nh, wq, alpha=qa), ops.gemm(nh, wk, head_dim=d), ops.gemm(nh, wv, trans_out=True)
+
+    for name, fn in (("layernorm+q+k+vt", three_proj), ("ln_qkv_projection", lambda: ops.ln_qkv_projection(x, gamma, beta, wcat, heads, qa))):
+        w, c = both(fn)
+        print(json.dumps({"case": name, "us": w, "us_cold": c, "tflops": round(flops / w * 1e-6, 1)}), flush=True)
+    # GroupNorm -> proj_in
+    x3 = x.reshape(B * Fr, T, C)
+    for name, fn in (("groupnorm+proj_in", lambda: ops.gemm(ops.groupnorm(x3, gamma, beta, 32, 1e-6, False).reshape(M, C), wo, bo)),
+                     ("gn_scale_shift+affine_linear320", lambda: ops.affine_linear320(x, ops.groupnorm_scale_shift(x3, gamma, beta, 32, 1e-6), T, wo, bo))):
+        w, c = both(fn)
+        print(json.dumps({"case": name, "us": w, "us_cold": c, "tflops": round(2 * M * C * C / w * 1e-6, 1)}), flush=True)
 
 
 if __name__ == "__main__":

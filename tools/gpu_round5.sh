@@ -18,7 +18,7 @@ for STEP in "$@"; do
   env:*) export "${STEP#env:}"; echo "exported ${STEP#env:}" ;;
   ktests:*)
     E=${STEP#ktests:}; N=$(echo "$E" | tr -c 'a-zA-Z0-9_' '_')
-    timeout 900 python -m pytest tests/test_hip_ops.py -m gpu -q -x -k "$E" > $OUT/ktests_$N.log 2>&1; echo "rc=$?" >> $OUT/ktests_$N.log
+    timeout 900 python -m pytest tests/test_hip_ops.py -m gpu -q -k "$E" > $OUT/ktests_$N.log 2>&1; echo "rc=$?" >> $OUT/ktests_$N.log
     grep -E "^FAILED|^ERROR|passed|failed|rc=|Error|error:|assert" $OUT/ktests_$N.log | tail -n 25 ;;
   fbench:*)
     N=${STEP#fbench:}
