@@ -103,6 +103,7 @@ __global__ __launch_bounds__(NT, (D > 96 ? 1 : 2)) void ref_attn_kernel(const Re
     qvalid[g] = q[g] < T;
   }
   const int ref = a.ref_index ? a.ref_index[n] : -1;
+  const int ns = a.frame_mod > 0 ? n % a.frame_mod : n;   // source frame of q / k / v^T (attn_args.h)
 
   // zero the padding that is never overwritten: K columns [D, DQ*16) and V^T rows [D, DO*32)
   for (int i = tid; i < 2 * KV * KROW; i += NT) (&sK[0][0])[i] = (f16)0.f;
@@ -116,7 +117,7 @@ __global__ __launch_bounds__(NT, (D > 96 ? 1 : 2)) void ref_attn_kernel(const Re
   f16x8 qf[QH][DQ];
 #pragma unroll
   for (int g = 0; g < QH; ++g) {
-    const f16* qp = a.q + ((int64_t)n * T + (qvalid[g] ? q[g] : 0)) * a.ldq + h * D;
+    const f16* qp = a.q + ((int64_t)ns * T + (qvalid[g] ? q[g] : 0)) * a.ldq + h * D;
 #pragma unroll
     for (int kk = 0; kk < DQ; ++kk) {
       const int d0 = kk * 16 + hi * 8;
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(NT, (D > 96 ? 1 : 2)) void ref_attn_kernel(const Re
     const int tt = second ? t - nts : t;
     const int64_t ldk = second ? a.ldkr : a.ldk;
     const int64_t ldv = second ? a.ldvtr : a.ldvt;
-    const int64_t tok0 = (int64_t)(second ? ref : n) * T + (int64_t)tt * KV;
+    const int64_t tok0 = (int64_t)(second ? ref : ns) * T + (int64_t)tt * KV;
     const f16* kb = (second ? a.kref : a.k) + tok0 * ldk + h * (second ? a.kr_hs : a.k_hs);
     const f16* vb = (second ? a.vtref : a.vt) + (int64_t)h * D * ldv + tok0;
     if (FAST) {
@@ -688,6 +689,9 @@ extern "C" int anip_ref_attention_ex(const void* q, int64_t ldq, const void* k, 
   a.ref_index = ref_index;
   a.out = (f16*)out; a.ldo = ldo;
   a.T = T; a.heads = heads;
+  a.frame_mod = (int)((unsigned)flags >> 16);
+  ANIP_REQUIRE(a.frame_mod == 0 || (a.frame_mod > 0 && Nf % a.frame_mod == 0), "anip_ref_attention: Nf=%d is not a multiple of the frame modulus %d",
+               Nf, a.frame_mod);
   const bool q_log2 = (flags & ANIP_ATTN_Q_LOG2_SCALED) != 0;   // scores are base-2 exponents already: `scale` is not applied
   a.scale_log2e = q_log2 ? 1.0f : scale * 1.4426950408889634f;
   a.vt_vec_ok = ((T & 7) == 0) && ((ldvt & 7) == 0);

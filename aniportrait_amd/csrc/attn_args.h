@@ -14,6 +14,7 @@ struct RefAttnArgs {
   int T, heads;
   float scale_log2e;
   int vt_vec_ok, vtref_vec_ok;
+  int frame_mod;   // > 0: frame n reads q / k / v^T of frame n % frame_mod (the two CFG halves share their self tokens); 0: of frame n
 };
 
 // attn_dma.hip: 1 if (a, d) is a shape the LDS-DMA kernel takes (the caller has checked flags), launches it; 0 = not taken

@@ -118,6 +118,7 @@ __global__ __launch_bounds__(NW * 64, (D <= 40 ? 4 : 2)) void ref_attn_dma_kerne
   }
   const int q0 = qb * (32 * NW) + wave * 32;  // first query of this wave
   const int ref = a.ref_index ? a.ref_index[n] : -1;
+  const int ns = a.frame_mod > 0 ? n % a.frame_mod : n;   // frame whose q / k / v^T this frame attends with (its own output row stays n)
   const int nts = T / KV;
   const int ntiles = nts * (ref >= 0 ? 2 : 1);
 
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(NW * 64, (D <= 40 ? 4 : 2)) void ref_attn_dma_kerne
   f16x8 qf[QH][DQ];
 #pragma unroll
   for (int g = 0; g < QH; ++g) {
-    const f16* qp = a.q + ((int64_t)n * T + q0 + 32 * g + ql) * a.ldq + h * D;
+    const f16* qp = a.q + ((int64_t)ns * T + q0 + 32 * g + ql) * a.ldq + h * D;
 #pragma unroll
     for (int kk = 0; kk < DQ; ++kk) {
       const int d0 = kk * 16 + hi * 8;
@@ -145,9 +146,9 @@ __global__ __launch_bounds__(NW * 64, (D <= 40 ? 4 : 2)) void ref_attn_dma_kerne
   }
 
   // ---- DMA sources: piece p = wave + 8 i of a tile ([0, KP): K, [KP, NP): V^T; LDS destination stage + 1024 p either way) ----
-  const f16* kb_s = a.k + (int64_t)n * T * a.ldk + (int64_t)h * a.k_hs;
+  const f16* kb_s = a.k + (int64_t)ns * T * a.ldk + (int64_t)h * a.k_hs;
   const f16* kb_r = ref >= 0 ? a.kref + (int64_t)ref * T * a.ldkr + (int64_t)h * a.kr_hs : kb_s;
-  const f16* vb_s = a.vt + (int64_t)h * D * a.ldvt + (int64_t)n * T;
+  const f16* vb_s = a.vt + (int64_t)h * D * a.ldvt + (int64_t)ns * T;
   const f16* vb_r = ref >= 0 ? a.vtref + (int64_t)h * D * a.ldvtr + (int64_t)ref * T : vb_s;
   const char* base_s[NPW];              // wave-uniform: operand base of the piece (self / reference segment)
   const char* base_r[NPW];

@@ -13,6 +13,17 @@
 // loaded straight into registers (no per-K-tile drain) was built and measured: 516 us vs 440 us for this kernel
 // (profiles/r02: exp_ffn) — the G phase is not latency-bound, so the variant was dropped.
 //
+// Round 5: (a) the block's LayerNorm moved into the prologue (ffn_geglu_kernel<C, LN = true>, anip_ffn_geglu_ln: no layernorm
+// launch, one input tensor): 423 -> 387 us per layer, 250 layers per clip.  (b) The W1 ring of DESIGN 5.3 was built — 32-deep
+// tiles through five 8-KB slots, three tiles ahead of the compute under counted vmcnt, the H tile in the two slots of a chunk's
+// last tiles, W2 waited for by queue order alone: x 80 + ring 40 + W2 40 = 160 KB — parity-green, 166 instead of 246 VGPRs, and
+// NO faster: 385 / 401 us (warm / cold) against 389 / 424 for this two-stage form, whole clip 1288.7 | 1273.7 | 1276.3 ms
+// ring | stages | ring inside one call (profiles/r05/e_*).  The kernel moves 2.46 MB of weights through LDS-DMA per 128 rows =
+// 2.5 GB per launch = 6.4 TB/s: that is the chip's LDS-DMA rate for weights every CU re-reads out of L2 (MI355X_MICROARCH.md,
+// "ldsdma-fill"), not the latency of a transfer — which confirms round 2's result ("the G phase is not latency-bound") and
+// retires the idea; the ring was removed again.  Fewer weight bytes per row need a taller row block, and 256 rows of x are
+// 160 KB by themselves.
+//
 // Why: at C = 320 (the 64x64 level) the two GEMMs cost 332 + 194 us per layer and are bound by memory traffic, not by
 // the matrix pipe: the GEGLU output H (M x 4C fp16 = 335 MB) is written to HBM and read back, and the second GEMM
 // streams it as its A operand.  Here H never leaves the CU.
@@ -27,8 +38,6 @@
 //     burst per chunk issued while G is being computed); 80 accumulator VGPRs per wave (64 x 80 wave tile);
 //   * epilogue: + b2 + residual, 16-B stores (v_permlane16_swap pairs of tiles, as in gemm2).
 // LDS: 80 + 32 + 40 = 152 KB -> one block per CU.  Global->LDS traffic per block: 80 KB (x) + 20 x 120 KB (W1, W2).
-#include <stdlib.h>
-
 #include "common.h"
 
 // GEGLU activation of the epilogues: gelu_poly_f (FMA pipe only; default) or, with -DANIP_GELU_EXACT, gelu_fast_f (A&S erf,
@@ -64,13 +73,7 @@ struct FfnArgs {
   float eps;
 };
 
-// RING (round 5): W1 travels as 32-deep tiles (128 packed rows x 64 B = 8 KB, one LDS-DMA piece per wave) through a 5-slot ring,
-// THREE tiles ahead of the compute under counted vmcnt — the 64-deep two-stage form drains the queue (vmcnt(0)) at every K-tile
-// with one tile of look-ahead: 512 MFMA cycles per SIMD against an L2 -> LDS round trip of 1200-2000, the waves parked at the
-// rendezvous 48 % of the time (SQ_WAIT_ANY, profiles/r05/b_pmck_fused_summary.json).  A chunk is 10 tiles, so tile s of every
-// chunk lives in slot s % 5; the two slots of the chunk's last tiles (3, 4: 16 KB, contiguous) take the H tile, while the three
-// tiles already in flight for the next chunk land in slots 0-2.  x 80 KB + ring 40 KB + W2 chunk 40 KB = 160 KB exactly.
-template <int C_, bool LN, bool RING>
+template <int C_, bool LN>
 __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs a) {
   constexpr int BM = 128;
   constexpr int KT = C_ / 64;            // 64-deep K-tiles of x / W1
@@ -79,10 +82,7 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs a) {
   constexpr int PLANE = BM * 128;        // bytes of one [128][128 B] LDS image
   constexpr int XS = KT * PLANE;         // x planes
   constexpr int W1S = XS;                // two W1 stages
-  constexpr int RSLOT = 8192, NRS = 5;   // RING: W1 ring slot (128 rows x 64 B), slots
-  constexpr int NT32 = NCHUNK * (C_ / 32);  // RING: 32-deep W1 tiles in all
-  constexpr int W2S = W1S + (RING ? NRS * RSLOT : 2 * PLANE);   // W2 chunk: [C_][128 B]
-  static_assert(!RING || (C_ / 32) % NRS == 0, "a chunk must be a whole number of ring turns");
+  constexpr int W2S = W1S + 2 * PLANE;   // W2 chunk: [C_][128 B]
   constexpr int FN = C_ / 4 / 16;        // output 16-col tiles per wave (wave tile 64 x C_/4)
   static_assert(C_ % 64 == 0 && (C_ / 4) % 16 == 0, "unsupported width");
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -118,14 +118,6 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs a) {
                                                0, 0);
     }
   };
-  // RING: 32-deep tile u of the whole W1 stream = tile u % 10 of chunk u / 10: ONE piece per wave, 16 rows x 64 B, the bank
-  // swizzle of 64-B rows (chunk ^= 2 * bit3(row), as gemm2.hip's BK = 32 tiles) on the source side
-  auto issue_w1r = [&](int u) {
-    const int cu = u / (C_ / 32), su = u - cu * (C_ / 32);
-    const int lrr = lane >> 2, lsr = lane & 3;
-    const uint32_t vo = (uint32_t)(((cu * 128 + wave * 16 + lrr) * C_ + su * 32) * 2 + ((lsr ^ (((lrr >> 3) & 1) * 2)) << 4));
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW1, FFN_LDS_PTR(smem + W1S + (u % NRS) * RSLOT + wave * 1024), 16, vo, 0, 0, 0);
-  };
   auto issue_w2 = [&](int chunk) {                             // C_ rows x 64 k of W2: C_/8 instructions, C_/64 per wave
 #pragma unroll
     for (int i = 0; i < C_ / 64; ++i) {
@@ -154,19 +146,11 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs a) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) oacc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  auto issue_w1_first = [&]() {
-    if constexpr (RING) {
-#pragma unroll
-      for (int u = 0; u < 3; ++u) issue_w1r(u);
-    } else {
-      issue_w1(0, 0, 0);
-    }
-  };
   if constexpr (LN) {
     // LayerNorm in the prologue (round 5): four lanes per row (16-B chunks part, part + 4, ..), statistics from registers, the
     // normalised row written as fp16 into the same swizzled planes the LDS-DMA path fills — the stand-alone layernorm launch
     // (84 MB read + 84 MB written per 64x64 layer) and the second input tensor are gone.  W1's first tile streams meanwhile.
-    issue_w1_first();
+    issue_w1(0, 0, 0);
     constexpr int NCH = C_ / 8 / 4;            // chunks per lane
     const int row = tid >> 2, part = tid & 3;
     const int m = m0 + row;
@@ -210,11 +194,11 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs a) {
   } else {
 #pragma unroll
     for (int kt = 0; kt < KT; ++kt) issue_x(kt);
-    issue_w1_first();
+    issue_w1(0, 0, 0);
   }
 
   for (int c = 0; c < NCHUNK; ++c) {
-    const int base = c & 1;                                    // !RING: K-tile kt of this chunk lives in stage (kt + base) & 1
+    const int base = c & 1;                                    // K-tile kt of this chunk lives in stage (kt + base) & 1
     // GEGLU bias of this wave's 16 hidden units (value at packed row r, gate at r + 16)
     float bv[4], bg[4];
 #pragma unroll
@@ -226,34 +210,6 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) gacc[i][0] = gacc[i][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    if constexpr (RING) {
-      const int wko = (fq ^ (((fr >> 3) & 1) * 2)) << 4;       // 16-B slot of k-group fq in a 64-B ring row
-#pragma unroll
-      for (int s_ = 0; s_ < C_ / 32; ++s_) {
-        const int t = c * (C_ / 32) + s_;
-        // tile t of this wave has landed: in flight behind it stay tiles t + 1, t + 2 — and, at steps 1 and 2 of a chunk, the
-        // C_/64 pieces of its W2 chunk, issued at step 0 between tile t + 2 and tile t + 3 (the queue completes in order, so W2
-        // is complete from step 3 on without a wait of its own)
-        if (c == NCHUNK - 1 && s_ >= C_ / 32 - 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (s_ == 1 || s_ == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 + C_ / 64) : "memory");
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // tile t complete for all waves; the slot read at step t - 2 (and, at s_ = 0, H and W2 of the O phase) is free
-        asm volatile("" ::: "memory");
-        if (s_ == 0) issue_w2(c);
-        if (t + 3 < NT32) issue_w1r(t + 3);
-        const char* xs = smem + (s_ >> 1) * PLANE;
-        const char* ws = smem + W1S + (s_ % NRS) * RSLOT;
-        const int ko = (s_ & 1) ? ko1 : ko0;
-        const f16x8 b0 = *(const f16x8*)(ws + (wn * 32 + fr) * 64 + wko);
-        const f16x8 b1 = *(const f16x8*)(ws + (wn * 32 + 16 + fr) * 64 + wko);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const f16x8 af = *(const f16x8*)(xs + a_row + i * 16 * 128 + ko);
-          gacc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b0, af, gacc[i][0], 0, 0, 0);
-          gacc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(b1, af, gacc[i][1], 0, 0, 0);
-        }
-      }
-    } else {
     for (int kt = 0; kt < KT; ++kt) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();   // W1(c, kt) (and x, W2 pieces) landed for all waves; previous reads are complete
@@ -274,11 +230,10 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs a) {
         }
       }
     }
-    }
-    // ---- GEGLU in registers -> H tile (fp16) into the stage that held the last K-tile (RING: ring slots 3 and 4) -------------
+    // ---- GEGLU in registers -> H tile (fp16) into the stage that held the last K-tile -------------------------
     //   gacc[i][j][r] = G[row wm*64 + i*16 + fr][packed col wn*32 + j*16 + fq*4 + r], j = 0 value / 1 gate
     __builtin_amdgcn_s_barrier();     // every wave is done reading that stage
-    char* hs = smem + W1S + (RING ? 3 * RSLOT : ((KT - 1 + base) & 1) * PLANE);
+    char* hs = smem + W1S + ((KT - 1 + base) & 1) * PLANE;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       union { u32x2 u; f16 e[4]; } t;
@@ -288,10 +243,9 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs a) {
       // hidden unit wn*16 + fq*4 .. +3 of the chunk: 16-B slot (wn*2 + fq/2) ^ (row & 7), byte (fq & 1) * 8 in it
       *(u32x2*)(hs + row * 128 + (((wn * 2 + (fq >> 1)) ^ (row & 7)) << 4) + (fq & 1) * 8) = t.u;
     }
-    if constexpr (!RING)
-      if (c + 1 < NCHUNK) issue_w1(c + 1, 0, (base ^ 1) & 1);   // next chunk's first K-tile -> the other stage (read last at kt = KT-2)
+    if (c + 1 < NCHUNK) issue_w1(c + 1, 0, (base ^ 1) & 1);   // next chunk's first K-tile -> the other stage (read last at kt = KT-2)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();     // H complete; W2 chunk landed (every wave drained its pieces at the kt >= 1 waits / by step 3)
+    __builtin_amdgcn_s_barrier();     // H complete; W2 chunk landed (every wave drained its pieces at the kt >= 1 waits)
     // ---- out += H · W2c^T (K = 64) -----------------------------------------------------------------------------
     const char* w2s = smem + W2S;
 #pragma unroll
@@ -424,30 +378,6 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnArgs a) {
   }
 }
 
-// ANIP_FFN_RING=0: the two-stage 64-deep W1 form (A/B switch of round 5's measurement)
-template <bool LN>
-int ffn_launch(const FfnArgs& a, int64_t M, void* stream, const char* who) {
-  static const bool ring = getenv("ANIP_FFN_RING") ? atoi(getenv("ANIP_FFN_RING")) != 0 : true;
-  const int lds = 320 / 64 * 128 * 128 + (ring ? 5 * 8192 : 2 * 128 * 128) + 320 * 128;   // x planes + W1 ring / stages + W2 chunk
-  const void* fn = ring ? (const void*)ffn_geglu_kernel<320, LN, true> : (const void*)ffn_geglu_kernel<320, LN, false>;
-  if (anip_raise_lds_limit(fn, lds) != 0) {
-    anip_set_error("%s: cannot raise the dynamic LDS limit to %d bytes", who, lds);
-    return -2;
-  }
-  {
-    AnipProfScope prof_(ANIP_K_GEMM, stream);
-    const dim3 grid((unsigned)((M + 127) / 128));
-    if (ring) hipLaunchKernelGGL((ffn_geglu_kernel<320, LN, true>), grid, dim3(512), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((ffn_geglu_kernel<320, LN, false>), grid, dim3(512), lds, (hipStream_t)stream, a);
-  }
-  hipError_t e__ = hipGetLastError();
-  if (e__ != hipSuccess) {
-    anip_set_error("%s: launch failed: %s", who, hipGetErrorString(e__));
-    return -2;
-  }
-  return 0;
-}
-
 }  // namespace
 
 extern "C" int anip_ffn_geglu(const void* x, const void* w1p, const float* b1p, const void* w2, const float* b2,
@@ -461,7 +391,17 @@ extern "C" int anip_ffn_geglu(const void* x, const void* w1p, const float* b1p, 
   a.x = (const f16*)x; a.w1p = (const f16*)w1p; a.b1p = b1p; a.w2 = (const f16*)w2; a.b2 = b2;
   a.res = (const f16*)residual; a.out = (f16*)out; a.M = (int)M;
   a.gamma = nullptr; a.beta = nullptr; a.eps = 0.f;
-  return ffn_launch<false>(a, M, stream, "anip_ffn_geglu");
+  constexpr int LDS = (320 / 64 + 2) * 128 * 128 + 320 * 128;
+  if (anip_raise_lds_limit((const void*)ffn_geglu_kernel<320, false>, LDS) != 0) {
+    anip_set_error("anip_ffn_geglu: cannot raise the dynamic LDS limit to %d bytes", LDS);
+    return -2;
+  }
+  {
+    AnipProfScope prof_(ANIP_K_GEMM, stream);
+    hipLaunchKernelGGL((ffn_geglu_kernel<320, false>), dim3((unsigned)((M + 127) / 128)), dim3(512), LDS, (hipStream_t)stream, a);
+  }
+  ANIP_LAUNCH_CHECK("anip_ffn_geglu");
+  return 0;
 }
 
 // out = residual + FeedForward(LayerNorm(x; gamma, beta, eps)) — the LayerNorm applied while the x tile is staged
@@ -477,5 +417,15 @@ extern "C" int anip_ffn_geglu_ln(const void* x, const float* gamma, const float*
   a.x = (const f16*)x; a.w1p = (const f16*)w1p; a.b1p = b1p; a.w2 = (const f16*)w2; a.b2 = b2;
   a.res = (const f16*)residual; a.out = (f16*)out; a.M = (int)M;
   a.gamma = gamma; a.beta = beta; a.eps = eps;
-  return ffn_launch<true>(a, M, stream, "anip_ffn_geglu_ln");
+  constexpr int LDS = (320 / 64 + 2) * 128 * 128 + 320 * 128;
+  if (anip_raise_lds_limit((const void*)ffn_geglu_kernel<320, true>, LDS) != 0) {
+    anip_set_error("anip_ffn_geglu_ln: cannot raise the dynamic LDS limit to %d bytes", LDS);
+    return -2;
+  }
+  {
+    AnipProfScope prof_(ANIP_K_GEMM, stream);
+    hipLaunchKernelGGL((ffn_geglu_kernel<320, true>), dim3((unsigned)((M + 127) / 128)), dim3(512), LDS, (hipStream_t)stream, a);
+  }
+  ANIP_LAUNCH_CHECK("anip_ffn_geglu_ln");
+  return 0;
 }

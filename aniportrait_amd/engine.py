@@ -221,6 +221,8 @@ _FUSED_TEMPORAL = os.environ.get("ANIP_FUSED_TEMPORAL", "1") == "1"
 # row-stationary projections at C = 320 (csrc/tblock.hip): norm1 -> to_q | to_k | to_v^T as one launch, and GroupNorm's apply
 # inside proj_in (statistics finalised into a per-frame affine table).  ANIP_FUSED_ROWS=0 selects the separate launches.
 _FUSED_ROWS = os.environ.get("ANIP_FUSED_ROWS", "1") == "1"
+# unet_forward(cfg_shared_input=True): the CFG pair's identical prefix computed once.  ANIP_SHARE_CFG_PREFIX=0: both halves.
+_SHARE_CFG_PREFIX = os.environ.get("ANIP_SHARE_CFG_PREFIX", "1") == "1"
 
 
 def transformer_in(net, p, x):
@@ -306,13 +308,18 @@ def prepare_reference(net, cfg, refs, ehs, attn2_cache, attn2_slot=0):
     attn2_cache.get(net, cfg, ehs, refresh=True, slot=attn2_slot)
 
 
-def transformer_block(net, p, h, Nf, T, heads, attn2_vec, rows_per_sample, ref=None, ref_index=None, stop_after_bank=False):
+def transformer_block(net, p, h, Nf, T, heads, attn2_vec, rows_per_sample, ref=None, ref_index=None, stop_after_bank=False, dup=1):
     """(Temporal)BasicTransformerBlock under ReferenceAttentionControl
-    (src/models/attention.py:383-445, src/models/mutual_self_attention.py:93-265).  h (Nf*T, C)."""
+    (src/models/attention.py:383-445, src/models/mutual_self_attention.py:93-265).  h (Nf*T, C).
+    dup = 2 (read mode, CFG pair with identical inputs — unet_forward's cfg_shared_input): h holds the Nf / 2 frames the two
+    halves share; norm1 and the q / k / v projections run once, the attention reads them for both halves (frame n attends with
+    the tokens of frame n % (Nf / 2), each with its own reference index), and from the attention output on the block carries all
+    Nf frames: the output projection runs per half against the shared residual.  Returns (Nf*T, C)."""
     C = h.shape[1]
     d = C // heads
     M = h.shape[0]
     mode = ref.mode if ref is not None else "plain"
+    assert dup == 1 or (dup == 2 and mode != "write" and M * 2 == Nf * T)
     qa = ops.attn_q_alpha(d)
     # Q token-major, multiplied by d^-1/2 log2(e) in its projection (the GEMM's alpha: still one fp16 rounding of the fp32
     # accumulator; the attention kernel then exponentiates q.k in base 2 with no per-score multiply); K HEAD-MAJOR (heads,
@@ -339,25 +346,41 @@ def transformer_block(net, p, h, Nf, T, heads, attn2_vec, rows_per_sample, ref=N
         assert ref.bank.shape[1] == T, "reference bank token count differs from the denoising latents"
         kw = dict(kref=ref.kref, ldkr=d, kref_head_stride=ref.kref.shape[0] * d, vtref=ref.vtref,
                   ldvtr=ref.vtref.shape[1], ref_index=ref_index[0], n_ref_frames=ref_index[1])
-    a = ops.ref_attention(q, C, k, d, vt, vt.shape[1], Nf, T, heads, d, k_head_stride=Nf * T * d, q_log2_scaled=True, **kw)
+    a = ops.ref_attention(q, C, k, d, vt, vt.shape[1], Nf, T, heads, d, k_head_stride=M * d, q_log2_scaled=True,
+                          frame_mod=Nf // dup if dup > 1 else 0, **kw)
     # attn1 out-proj + residual (+ the collapsed attn2: one vector per sample)
-    h = ops.gemm(a, net.lin(p + ".attn1.to_out.0.weight"), net.f32(p + ".attn1.to_out.0.bias"),
-                 rowbias=attn2_vec, rows_per_group=rows_per_sample, residual=h)
+    if dup == 1:
+        h = ops.gemm(a, net.lin(p + ".attn1.to_out.0.weight"), net.f32(p + ".attn1.to_out.0.bias"),
+                     rowbias=attn2_vec, rows_per_group=rows_per_sample, residual=h)
+    else:
+        full = torch.empty((Nf * T, C), dtype=F16, device=h.device)
+        for s_ in range(dup):           # one CFG half = one sample: its attn2 vector, the shared residual
+            ops.gemm(a[s_ * M:(s_ + 1) * M], net.lin(p + ".attn1.to_out.0.weight"), net.f32(p + ".attn1.to_out.0.bias"),
+                     rowbias=None if attn2_vec is None else attn2_vec[s_:s_ + 1], rows_per_group=rows_per_sample, residual=h,
+                     out=full[s_ * M:(s_ + 1) * M])
+        h = full
     return feed_forward(net, p + ".ff", h, p + ".norm3")
 
 
 def spatial_transformer(net, p, x, heads, attn2_vec, frames_per_sample, ref=None, ref_index=None,
-                        stop_after_bank=False):
-    """Transformer3DModel / Transformer2DModel (src/models/transformer_3d.py:103-169): x (N,H,W,C)."""
+                        stop_after_bank=False, dup=1):
+    """Transformer3DModel / Transformer2DModel (src/models/transformer_3d.py:103-169): x (N,H,W,C).
+    dup = 2: x holds the N frames the two CFG halves share -> (2 N, H, W, C) (see transformer_block)."""
     N, H, W, C = x.shape
     T = H * W
     h = transformer_in(net, p, x)
-    h = transformer_block(net, p + ".transformer_blocks.0", h, N, T, heads, attn2_vec, frames_per_sample * T,
-                          ref, ref_index, stop_after_bank)
+    h = transformer_block(net, p + ".transformer_blocks.0", h, N * dup, T, heads, attn2_vec, frames_per_sample * T,
+                          ref, ref_index, stop_after_bank, dup)
     if h is None:
         return None
-    out = ops.gemm(h, net.lin(p + ".proj_out.weight"), net.f32(p + ".proj_out.bias"), residual=x.reshape(N * T, C))
-    return out.reshape(N, H, W, C)
+    if dup == 1:
+        out = ops.gemm(h, net.lin(p + ".proj_out.weight"), net.f32(p + ".proj_out.bias"), residual=x.reshape(N * T, C))
+        return out.reshape(N, H, W, C)
+    out = torch.empty((dup * N * T, C), dtype=F16, device=x.device)
+    for s_ in range(dup):
+        ops.gemm(h[s_ * N * T:(s_ + 1) * N * T], net.lin(p + ".proj_out.weight"), net.f32(p + ".proj_out.bias"),
+                 residual=x.reshape(N * T, C), out=out[s_ * N * T:(s_ + 1) * N * T])
+    return out.reshape(dup * N, H, W, C)
 
 
 def motion_module(net, p, x, b, f, heads):
@@ -471,7 +494,8 @@ class Attn2Cache:
 
 
 def unet_forward(net, cfg, x, b, f, t, ehs, attn2_cache, refs, with_motion, ref_index=None, pose_nhwc=None,
-                 final=True, stop_after_last_bank=False, temb_in=None, attn2_refresh=True, tap=None, attn2_slot=0):
+                 final=True, stop_after_last_bank=False, temb_in=None, attn2_refresh=True, tap=None, attn2_slot=0,
+                 cfg_shared_input=False):
     """UNet3DConditionModel.forward (src/models/unet_3d.py:399-580) / the ReferenceNet
     UNet2DConditionModel.forward (src/models/unet_2d_condition.py:872-1308, f = 1, no motion modules).
 
@@ -480,6 +504,11 @@ def unet_forward(net, cfg, x, b, f, t, ehs, attn2_cache, refs, with_motion, ref_
     (src/models/mutual_self_attention.py:77-85,166-186), and the number n of frames that do have one.  pose_nhwc: list of 5 channels-last tensors or None.  Returns (b*f, h, w, out_channels) fp16 (or the last hidden state if
     `final` is False; None if `stop_after_last_bank`).  tap(name, x): optional observer of every block output
     (channels-last; tools/bisect_parity.py compares them with the oracle's, block by block).
+    cfg_shared_input: the caller GUARANTEES that the b = 2 samples are a classifier-free-guidance pair built by duplication —
+    identical x, pose features and timestep (pipeline_pose2vid_long.py:521-536: `latent_model_input = torch.cat([latents] * 2)`,
+    the pose features repeated, one t); they differ in encoder_hidden_states (which enters behind attn1 only) and in their
+    reference index.  Then everything in front of the first reference attention — the first ResnetBlock3D, the transformer's
+    GroupNorm + proj_in, norm1 and the q / k / v projections — is the same for both halves and runs ONCE on f frames.
     """
     if ehs.shape[1] != 1:
         raise NotImplementedError("encoder_hidden_states with sequence length != 1: the pose2vid path feeds "
@@ -537,8 +566,19 @@ def unet_forward(net, cfg, x, b, f, t, ehs, attn2_cache, refs, with_motion, ref_
                         residual=None if pose_nhwc is None else pose_nhwc[0])
     see("conv_in", x)
     skips = [x]
+    p00 = "down_blocks.0.attentions.0"
+    share = (cfg_shared_input and _SHARE_CFG_PREFIX and b == 2 and _DOWN_HAS_ATTN[0] and gn_frames == 1 and tap is None and
+             not stop_after_last_bank and refs.get(p00) is not None and refs[p00].mode == "read" and ref_index is not None)
     for i in range(nblk):
         for j in range(lpb):
+            if share and i == 0 and j == 0:
+                # the CFG halves' shared prefix: first resnet + norm / proj_in / norm1 / q | k | v on the f frames of ONE half
+                o, c = toffs["down_blocks.0.resnets.0.time_emb_proj"]
+                r0 = resnet(net, "down_blocks.0.resnets.0", x[:f], None, temb_all[:1, o:o + c], f * H * W, eps, groups, 1)
+                x = spatial_transformer(net, p00, r0, heads, a2[p00], f, refs.get(p00), ref_index, dup=2)
+                x = mm("down_blocks.0.motion_modules.0", x)
+                skips.append(x)
+                continue
             x = res(f"down_blocks.{i}.resnets.{j}", x)
             if _DOWN_HAS_ATTN[i]:
                 x = attn(f"down_blocks.{i}.attentions.{j}", x)

@@ -548,8 +548,10 @@ def batchnorm(x, gamma, beta, running_mean=None, running_var=None, eps=1e-5, rel
 
 
 def ref_attention(q, ldq, k, ldk, vt, ldvt, n_frames, T, heads, d, kref=None, ldkr=0, vtref=None, ldvtr=0,
-                  ref_index=None, scale=None, n_ref_frames=0, k_head_stride=0, kref_head_stride=0, q_log2_scaled=False):
-    """see anip_ref_attention_ex; returns (n_frames*T, heads*d) fp16.  `n_ref_frames` (frames whose
+                  ref_index=None, scale=None, n_ref_frames=0, k_head_stride=0, kref_head_stride=0, q_log2_scaled=False,
+                  frame_mod=0):
+    """see anip_ref_attention_ex; returns (n_frames*T, heads*d) fp16.  frame_mod = m > 0: q / k / vt hold m frames, frame n
+    attends with those of frame n % m (ANIP_ATTN_FRAME_MOD).  `n_ref_frames` (frames whose
     ref_index >= 0) is only used for the profiler's FLOP count.  k / kref head-major (gemm(head_dim=d) output, shape
     (heads, tokens, d)): ldk = d and k_head_stride = tokens * d.  q_log2_scaled: q already carries scale * log2(e)
     (ANIP_ATTN_Q_LOG2_SCALED: gemm(..., alpha=attn_q_alpha(d)) of the to_q projection)."""
@@ -562,7 +564,8 @@ def ref_attention(q, ldq, k, ldk, vt, ldvt, n_frames, T, heads, d, kref=None, ld
         scale = d ** -0.5
     L.check(lib.anip_ref_attention_ex(_p(q), ldq, _p(k), ldk, _p(vt), ldvt, _p(kref), ldkr, _p(vtref), ldvtr,
                                       _p(ref_index), _p(out), heads * d, n_frames, T, heads, d, float(scale),
-                                      int(k_head_stride), int(kref_head_stride), 1 if q_log2_scaled else 0, _stream()),
+                                      int(k_head_stride), int(kref_head_stride),
+                                      (1 if q_log2_scaled else 0) | (int(frame_mod) << 16), _stream()),
             "anip_ref_attention")
     return out
 

@@ -101,8 +101,9 @@ class _DenoiseRunner:
             self.x[s_ * self.f:(s_ + 1) * self.f].copy_(x)
 
     def _forward(self):
+        # (S == 2: `_fill_x` writes the same latents into both halves, the pose features are repeated, the sinusoid rows are equal)
         return self.unet.forward_nhwc(self.x, self.S, self.f, None, self.ehs, self.pose, temb_in=self.temb,
-                                      attn2_refresh=False)
+                                      attn2_refresh=False, cfg_shared_input=self.S == 2)
 
     def eager(self, x, temb):
         """un-captured forward (profilers / ANIP_NO_GRAPH): same static buffers, same in-place reference state"""
@@ -348,10 +349,29 @@ class Pose2VideoPipeline(_Base):
 
     # -- stages ---------------------------------------------------------------------------------------
     def _clip_embeds(self, ref_image, device):
+        """CLIP image embedding of the reference image (pipeline_pose2vid_long.py:379-385).  The encoder is the transformers
+        module as given (outside the HIP scope); on the GPU its forward — a few hundred small launches, 9-10 ms of host-bound
+        launching per clip next to a 1.27 s clip — is captured once per encoder / input shape into a hipGraph and replayed
+        (same kernels, same result).  A module that cannot be captured (capture error) runs eagerly from then on."""
         clip_image = self.clip_image_processor.preprocess(ref_image.resize((224, 224)), return_tensors="pt").pixel_values
         enc = self.image_encoder
         p = next(enc.parameters())
-        return enc(clip_image.to(p.device, dtype=p.dtype)).image_embeds.to(device)
+        x = clip_image.to(p.device, dtype=p.dtype)
+        st = self.__dict__.setdefault("_clip_graph", {})
+        if (p.device.type == "cuda" and not os.environ.get("ANIP_NO_GRAPH") and not st.get("failed")
+                and not torch.cuda.is_current_stream_capturing()):
+            key = (id(enc), tuple(x.shape), x.dtype, str(p.device), p.data_ptr())
+            if st.get("key") != key:
+                st.clear()
+                st["key"] = key
+                st["fn"] = _GraphedFn(lambda px: [enc(px).image_embeds], [x])
+            try:
+                return st["fn"]([x])[0].clone().to(device)
+            except RuntimeError:
+                st.clear()
+                st["failed"] = True
+                torch.cuda.synchronize(p.device)
+        return enc(x).image_embeds.to(device)
 
     def _fused_step_coefficients(self, t):
         sch = self.scheduler
@@ -389,6 +409,7 @@ class Pose2VideoPipeline(_Base):
         self.__dict__["_runners"] = OrderedDict()
         self.__dict__.pop("_runner_tag", None)
         self.__dict__["_aux_graphs"] = {}
+        self.__dict__["_clip_graph"] = {}
         for name in ("denoising_unet", "reference_unet"):
             drop = getattr(getattr(self, name, None), "drop_reference_pools", None)
             if drop is not None:

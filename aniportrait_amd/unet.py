@@ -137,18 +137,20 @@ class _UNetBase(HipModel):
                                  attn2_slot)
 
     def forward_nhwc(self, x, b, f, timestep, encoder_hidden_states, pose_nhwc=None, final=True,
-                     stop_after_last_bank=False, temb_in=None, attn2_refresh=True, tap=None, ref_index=None, attn2_slot=0):
+                     stop_after_last_bank=False, temb_in=None, attn2_refresh=True, tap=None, ref_index=None, attn2_slot=0,
+                     cfg_shared_input=False):
         """channels-last entry used by the pipeline: x (b*f, h, w, C) fp16 on the GPU.  temb_in: device fp32
         (b, C0) timestep sinusoid replacing `timestep` (see engine.unet_forward).  attn2_refresh=False: reuse the
         collapsed-attn2 vectors the previous forward computed for this batch size (engine.Attn2Cache).  ref_index: explicit
         (int32 tensor (b*f,), number of frames with a reference) instead of the CFG layout derived from b / f — one CFG half
-        of a step run as its own forward; attn2_slot: that forward's own attn2 buffers."""
+        of a step run as its own forward; attn2_slot: that forward's own attn2 buffers.  cfg_shared_input: the b = 2 samples are a
+        CFG pair built by duplication (identical x, pose features, timestep) — see engine.unet_forward."""
         net = self.packed()
         refs = self._engine_refs()
         ridx = ref_index if ref_index is not None else self._ref_index(b, f, refs, net.device)
         out = engine.unet_forward(net, self.config, x, b, f, timestep, encoder_hidden_states, self._attn2_cache,
                                   refs, self.three_d, ridx, pose_nhwc, final, stop_after_last_bank, temb_in,
-                                  attn2_refresh, tap, attn2_slot)
+                                  attn2_refresh, tap, attn2_slot, cfg_shared_input)
         for p, rb in self._ref_blocks.items():  # write mode: append to module.bank like the hacked forward
             if rb.state.mode == "write" and rb.state.written is not None:
                 rb.node.bank.append(rb.state.written)

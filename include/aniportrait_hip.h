@@ -166,8 +166,14 @@ int anip_ref_attention(const void* q, int64_t ldq, const void* k, int64_t ldk, c
  * softmax and `scale` is ignored.  It is what the engine passes: for T % 256 == 0 and d in {40, 80, 160} it selects the
  * round-4 kernel (csrc/attn_dma.hip: LDS-DMA K / V^T ring, 256 queries per workgroup, running max folded into the score
  * MFMA at d = 40); every other shape runs the first kernel with the flag honoured.  The base-2 exponents must stay
- * below 6e4 in magnitude (the folded running max is carried as an fp16 hi/lo pair). */
+ * below 6e4 in magnitude (the folded running max is carried as an fp16 hi/lo pair).
+ * ANIP_ATTN_FRAME_MOD(m), m in [1, 32767]: q / k / vt hold m frames and frame n of the Nf (a multiple of m) attends with the
+ * tokens of frame n % m — the two classifier-free-guidance halves of a denoising call enter the first reference attention with
+ * identical self tokens (same latents, pose features and timestep; they differ in their reference index only), so the
+ * engine computes everything in front of it once (engine.unet_forward, cfg_shared_input).  Output and ref_index stay per
+ * frame n. */
 #define ANIP_ATTN_Q_LOG2_SCALED 1
+#define ANIP_ATTN_FRAME_MOD(m) ((int)(m) << 16)
 int anip_ref_attention_ex(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* vt, int64_t ldvt,
                           const void* kref, int64_t ldkr, const void* vtref, int64_t ldvtr,
                           const int* ref_index, void* out, int64_t ldo,

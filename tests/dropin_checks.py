@@ -40,9 +40,10 @@ def check_script_imports(script, last_line):
         mod = sys.modules[ns[name].__module__]
         assert os.path.abspath(mod.__file__).startswith(os.path.join(REFERENCE, "src") + os.sep), (name, mod.__file__)
     assert ns["save_videos_grid"].__module__ == "aniportrait_amd.video_io"   # the output side is shimmed too
-    for name in ("get_fps", "read_frames"):                              # not ours: the reference's own readers
-        if name in ns:
-            assert os.path.abspath(sys.modules[ns[name].__module__].__file__).startswith(os.path.join(REFERENCE, "src") + os.sep)
+    for name in ("get_fps", "read_frames"):                              # the pose-video readers: ours too (PyAV on first use),
+        if name in ns:                                                   # so that the import block never executes the reference's util.py
+            assert ns[name].__module__ == "aniportrait_amd.video_io", (name, ns[name].__module__)
+    assert "src.utils._reference_util" not in sys.modules               # (cv2 / torchvision / einops at its module level)
     from src.utils.util import crop_face                                 # not ours: falls through to the reference's module
     assert os.path.abspath(sys.modules[crop_face.__module__].__file__).startswith(os.path.join(REFERENCE, "src") + os.sep)
     for name in ("init_frame_interpolation_model", "batch_images_interpolation_tool"):   # the `-acc` plumbing is shimmed too

@@ -186,27 +186,29 @@ def batchnorm(x, gamma, beta, running_mean=None, running_var=None, eps=1e-5, rel
 
 
 def ref_attention(q, ldq, k, ldk, vt, ldvt, n_frames, T, heads, d, kref=None, ldkr=0, vtref=None, ldvtr=0,
-                  ref_index=None, scale=None, n_ref_frames=0, k_head_stride=0, kref_head_stride=0, q_log2_scaled=False):
+                  ref_index=None, scale=None, n_ref_frames=0, k_head_stride=0, kref_head_stride=0, q_log2_scaled=False,
+                  frame_mod=0):
     C = heads * d
+    nsrc = frame_mod if frame_mod else n_frames        # frames held by q / k / vt
     scale = d ** -0.5 if scale is None else scale
     if q_log2_scaled:       # q carries scale * log2(e): softmax of 2^(q.k)
         scale = 0.6931471805599453
-    Q = q[:, :C].float().reshape(n_frames, T, heads, d).permute(0, 2, 1, 3)
+    Q = q[:, :C].float().reshape(nsrc, T, heads, d).permute(0, 2, 1, 3)
     if k_head_stride:       # head-major (heads, tokens, d)
         k = k.reshape(heads, -1, d).permute(1, 0, 2).reshape(-1, C)
     if kref is not None and kref_head_stride:
         kref = kref.reshape(heads, -1, d).permute(1, 0, 2).reshape(-1, C)
-    K = k[:, :C].float().reshape(n_frames, T, heads, d).permute(0, 2, 1, 3)
-    V = vt.float().t().reshape(n_frames, T, heads, d).permute(0, 2, 1, 3)
+    K = k[:, :C].float().reshape(nsrc, T, heads, d).permute(0, 2, 1, 3)
+    V = vt.float().t().reshape(nsrc, T, heads, d).permute(0, 2, 1, 3)
     out = torch.empty((n_frames, T, C), dtype=F32)
     for n in range(n_frames):
-        Kn, Vn = K[n], V[n]
+        Kn, Vn = K[n % nsrc], V[n % nsrc]
         r = -1 if ref_index is None else int(ref_index[n])
         if r >= 0:
             Kr = kref[r * T:(r + 1) * T, :C].float().reshape(T, heads, d).permute(1, 0, 2)
             Vr = vtref.float().t()[r * T:(r + 1) * T].reshape(T, heads, d).permute(1, 0, 2)
             Kn, Vn = torch.cat([Kn, Kr], dim=1), torch.cat([Vn, Vr], dim=1)
-        p = torch.softmax(Q[n] @ Kn.transpose(-1, -2) * scale, dim=-1)
+        p = torch.softmax(Q[n % nsrc] @ Kn.transpose(-1, -2) * scale, dim=-1)
         out[n] = (p @ Vn).permute(1, 0, 2).reshape(T, C)
     return out.reshape(n_frames * T, C).to(F16)
 

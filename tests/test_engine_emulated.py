@@ -252,3 +252,39 @@ def test_row_stationary_branches_of_the_spatial_transformer_match_the_separate_l
         assert rel_err(outs[True][0], outs[False][0]) < 3e-3, mode
         if mode == "write":
             assert rel_err(outs[True][1], outs[False][1]) < 3e-3
+
+
+@torch.no_grad()
+def test_cfg_shared_prefix_of_the_denoising_unet_changes_nothing(emu, gold, monkeypatch):
+    """unet_forward(cfg_shared_input=True): the first ResnetBlock3D, the transformer's norm / proj_in, norm1 and the q / k / v
+    projections of down_blocks.0 run once for the two CFG halves (identical latents, pose features and timestep), the reference
+    attention reads them for both (frame n attends with the tokens of frame n % f) — same output as the full-batch walk, and
+    the reference-made golden still matches"""
+    from aniportrait_amd import engine
+    from golden_inputs import unet_case
+    from src.models.mutual_self_attention import ReferenceAttentionControl
+    m, _ = build_hip_models(True, keys=("denoising_unet", "reference_unet"), device="cpu")
+    c = unet_case(True)
+    wr = ReferenceAttentionControl(m["reference_unet"], do_classifier_free_guidance=True, mode="write", batch_size=1,
+                                   fusion_blocks="full")
+    rd = ReferenceAttentionControl(m["denoising_unet"], do_classifier_free_guidance=True, mode="read", batch_size=1,
+                                   fusion_blocks="full")
+    m["reference_unet"](c["ref_lat"].repeat(2, 1, 1, 1), torch.zeros((), dtype=torch.long),
+                        encoder_hidden_states=c["ehs"], return_dict=False)
+    rd.update(wr)
+    unet = m["denoising_unet"]
+    b, _, f, h, w = c["lat"].shape
+    x = c["lat"].permute(0, 2, 3, 4, 1).reshape(b * f, h, w, -1).half().contiguous()
+    pose = [gold[f"pose_fea/{i}"] for i in range(5)]
+    pose = [p_.permute(0, 2, 3, 4, 1).reshape(b * f, p_.shape[3], p_.shape[4], -1).half().contiguous() for p_ in pose]
+    assert torch.equal(x[:f], x[f:]) and all(torch.equal(p_[:f], p_[f:]) for p_ in pose)     # the guarantee the flag states
+    outs = {}
+    for shared in (False, True):
+        outs[shared] = unet.forward_nhwc(x, b, f, c["t"], c["ehs"], pose, cfg_shared_input=shared).float()
+    assert not torch.equal(outs[True][:f], outs[True][f:])            # the halves do diverge (reference index, attn2)
+    assert rel_err(outs[True], outs[False]) < 2e-3
+    want = gold["unet_out"].permute(0, 2, 3, 4, 1).reshape(b * f, h, w, -1).float()
+    assert rel_err(outs[True], want) < TOL
+    monkeypatch.setattr(engine, "_SHARE_CFG_PREFIX", False)
+    assert torch.equal(unet.forward_nhwc(x, b, f, c["t"], c["ehs"], pose, cfg_shared_input=True).float(), outs[False])
+    rd.clear(); wr.clear()

@@ -58,6 +58,20 @@ def test_refnet_banks_and_unet3d_match_reference(setup):
         assert out.sample.shape == c["lat"].shape and out.sample.dtype == torch.float32  # follows the input dtype
         assert out[0] is out.sample
         assert rel_err(out.sample.cpu(), gold["unet_out" if with_pose else "unet_out_nopose"]) < TOL
+    # the CFG pair's shared prefix (forward_nhwc(cfg_shared_input=True), what the pipeline's runner passes): first resnet,
+    # norm / proj_in, norm1 and q | k | v of down_blocks.0 once for both halves — same result as the full-batch walk, and the
+    # reference-made golden still matches; real width: M = 2 x 4 x 256 rows, through the row-stationary kernels
+    b_, _, f_, h_, w_ = c["lat"].shape
+    xn = c["lat"].permute(0, 2, 3, 4, 1).reshape(b_ * f_, h_, w_, -1).half().contiguous().to(DEV)
+    pn = [p_.permute(0, 2, 3, 4, 1).reshape(b_ * f_, p_.shape[3], p_.shape[4], -1).half().contiguous() for p_ in pose]
+    assert torch.equal(xn[:f_], xn[f_:]) and all(torch.equal(p_[:f_], p_[f_:]) for p_ in pn)
+    full = m["denoising_unet"].forward_nhwc(xn, b_, f_, c["t"], ehs.half(), pn)
+    shared = m["denoising_unet"].forward_nhwc(xn, b_, f_, c["t"], ehs.half(), pn, cfg_shared_input=True)
+    want = gold["unet_out"].permute(0, 2, 3, 4, 1).reshape(b_ * f_, h_, w_, -1)
+    print(f"cfg shared prefix ({'small' if small else 'real'}): vs full walk {rel_err(shared.float().cpu(), full.float().cpu()):.2e}, "
+          f"vs reference {rel_err(shared.float().cpu(), want):.2e}")
+    assert rel_err(shared.float().cpu(), full.float().cpu()) < 2e-3 and rel_err(shared.float().cpu(), want) < TOL
+    assert not torch.equal(shared[:f_], shared[f_:])
     # fp16 input -> fp16 output; deterministic
     o1 = m["denoising_unet"](c["lat"].half().to(DEV), c["t"], ehs.half(), pose_cond_fea=pose, return_dict=False)[0]
     o2 = m["denoising_unet"](c["lat"].half().to(DEV), c["t"], ehs.half(), pose_cond_fea=pose, return_dict=False)[0]

@@ -485,6 +485,30 @@ def test_temporal_attention(B, Fr, T, heads, d):
     close(out, o, f"temporal_attention B{B} F{Fr} T{T} h{heads} d{d}", rtol=4e-3, arms=4e-3)
 
 
+@pytest.mark.parametrize("d,T,heads", [(40, 256, 8), (80, 512, 4), (160, 256, 2), (40, 100, 8), (16, 64, 2)])
+def test_ref_attention_frame_modulus(d, T, heads):
+    """ANIP_ATTN_FRAME_MOD: q / k / v^T hold m frames and frame n of 2 m attends with the tokens of frame n % m under its own
+    reference index (the CFG halves' shared self tokens) — equal, bit for bit, to the call on the physically duplicated
+    operands; both kernels (LDS-DMA ring for T % 256 == 0, d in {40, 80, 160}; the first kernel otherwise)"""
+    ops = _ops()
+    m, Cc, Nref = 3, heads * d, 2
+    Nf = 2 * m
+    qs = (rnd(m * T, Cc, seed=170).float() * ops.attn_q_alpha(d)).half().to(DEV)
+    k = rnd(m * T, Cc, seed=171).to(DEV)
+    v = rnd(m * T, Cc, seed=172).to(DEV)
+    kref = rnd(Nref * T, Cc, seed=173).reshape(Nref * T, heads, d).permute(1, 0, 2).contiguous().to(DEV)
+    vtref = rnd(Nref * T, Cc, seed=174).t().contiguous().to(DEV)
+    ridx = torch.tensor([-1] * m + [1, 0, 1], dtype=torch.int32, device=DEV)
+    k_hm = k.reshape(m * T, heads, d).permute(1, 0, 2).contiguous()
+    kw = dict(kref=kref, ldkr=d, vtref=vtref, ldvtr=Nref * T, ref_index=ridx, kref_head_stride=Nref * T * d, q_log2_scaled=True)
+    got = ops.ref_attention(qs, Cc, k_hm, d, v.t().contiguous(), m * T, Nf, T, heads, d, k_head_stride=m * T * d, frame_mod=m, **kw)
+    q2, k2, v2 = qs.repeat(2, 1), k.repeat(2, 1), v.repeat(2, 1)
+    want = ops.ref_attention(q2, Cc, k2.reshape(Nf * T, heads, d).permute(1, 0, 2).contiguous(), d, v2.t().contiguous(), Nf * T, Nf,
+                             T, heads, d, k_head_stride=Nf * T * d, **kw)
+    assert tuple(got.shape) == (Nf * T, Cc) and torch.equal(got, want)
+    assert not torch.equal(got[:m * T], got[m * T:])            # the halves differ through their reference index
+
+
 def _tqkv_case(B, T, seed, wscale=1.0, with_pe=True):
     Fr, C, heads, d = 16, 320, 8, 40
     M = B * Fr * T

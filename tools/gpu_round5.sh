@@ -37,6 +37,10 @@ for STEP in "$@"; do
     timeout 600 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline > $OUT/qbench_$N.log 2>&1; echo "rc=$?"
     grep -o '"value": [0-9.]*' $OUT/qbench_$N.log | head -1; grep -o '"ms_per_step": [0-9.]*' $OUT/qbench_$N.log | head -1
     grep -E "Error|error|Traceback" $OUT/qbench_$N.log | head -5 ;;
+  tbench:*)   # tbench:<name> — 2 clips with ANIP_PIPE_TIMING=1 (synchronised wall time per pipeline stage) under the current environment
+    N=${STEP#tbench:}
+    ANIP_PIPE_TIMING=1 timeout 600 python bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-roofline > $OUT/tbench_$N.log 2>&1; echo "rc=$?"
+    grep -iE "refnet|unet|vae|pose|clip|total" $OUT/tbench_$N.log | tail -n 6 | cut -c1-400 ;;
   models)
     timeout 1200 python -m pytest tests/test_gpu_models.py -m gpu -q -x > $OUT/models.log 2>&1; echo "rc=$?" >> $OUT/models.log
     grep -E "^FAILED|^ERROR|passed|failed|rc=" $OUT/models.log | tail -n 12 ;;

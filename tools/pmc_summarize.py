@@ -41,8 +41,9 @@ def family(name):
         return "gemm_kernel<true> (conv3x3)" if conv else "gemm_kernel<false>"
     if "splitk_reduce" in name:
         return "gemm_kernel<false>"     # shared by the conv and the linear split-K; it carries no contraction
-    for key, fam in (("ref_attn", "ref_attn_kernel"), ("temporal_attn", "temporal_attn_kernel"), ("gn_stats", "gn_stats_kernel"),
-                     ("gn_apply", "gn_apply_kernel"), ("gn_slab", "gn_apply_kernel"), ("layernorm_kernel", "layernorm_kernel"), ("row_stats", "layernorm_kernel"), ("softmax_rows", "softmax_rows_kernel"),
+    for key, fam in (("ref_attn", "ref_attn_kernel"), ("temporal_qkv_attn", "gemm_kernel<false>"), ("rowgemm320", "gemm_kernel<false>"),
+                     ("temporal_attn", "temporal_attn_kernel"), ("gn_stats", "gn_stats_kernel"), ("gn_scale_shift", "gn_apply_kernel"),
+                     ("gn_apply", "gn_apply_kernel"), ("gn_slab", "gn_apply_kernel"), ("layernorm_kernel", "layernorm_kernel"), ("softmax_rows", "softmax_rows_kernel"),
                      ("conv_direct", "conv_small_kernel"), ("conv3x3_c4", "conv_small_kernel"), ("conv_small", "conv_small_kernel"), ("linear_small", "linear_small_kernel"),
                      ("bn_", "batchnorm_kernels"), ("ffn_geglu", "gemm_kernel<false>")):
         if key in name:
@@ -103,6 +104,7 @@ def main():
     fam = "--families" in sys.argv
     calls_file = sys.argv[sys.argv.index("--calls") + 1] if "--calls" in sys.argv else None
     rows = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))   # (kernel, grid) -> counter -> [sum, dispatches]
+    durs = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))   # (kernel, grid) -> file (= pass) -> [sum of dispatch ns, dispatches]
     for f in sorted(glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True)):
         with open(f, newline="") as fh:
             rd = csv.DictReader(fh)
@@ -111,17 +113,31 @@ def main():
             for r in rd:
                 key = (f, r.get("Dispatch_Id") or r.get("Correlation_Id"))
                 per_dispatch[(key, r["Counter_Name"])] += float(r["Counter_Value"])
-                meta[key] = (r["Kernel_Name"], r.get("Grid_Size", "?"))
+                meta[key] = (r["Kernel_Name"], r.get("Grid_Size", "?"), r.get("Start_Timestamp"), r.get("End_Timestamp"))
             for (key, cname), val in per_dispatch.items():
-                kn, grid = meta[key]
+                kn, grid = meta[key][:2]
                 a = rows[(demangle(kn), grid)][cname]
                 a[0] += val
                 a[1] += 1
+            for key, (kn, grid, t0, t1) in meta.items():
+                try:
+                    ns = float(t1) - float(t0)
+                except (TypeError, ValueError):
+                    continue
+                if ns > 0:
+                    d = durs[(demangle(kn), grid)][f]
+                    d[0] += ns
+                    d[1] += 1
     res = []
     for (kn, grid), ctrs in rows.items():
         launches = max(v[1] for v in ctrs.values())
         res.append(dict(kernel=kn, grid=grid, launches=launches, mean={c: v[0] / v[1] for c, v in ctrs.items()},
                         total={c: v[0] for c, v in ctrs.items()}, family=family(kn)))
+        # dispatch duration (kernel-trace timestamps of the same CSV) in the pass that carries GRBM_GUI_ACTIVE: busy cycles per
+        # XCD / duration = the clock the kernel actually ran at (the "clock-limited on real data" reading of DESIGN 5.3)
+        for f, (ns, n) in durs.get((kn, grid), {}).items():
+            if n and "GRBM_GUI_ACTIVE" in ctrs:
+                res[-1].setdefault("mean_dispatch_us_by_pass", {})[os.path.basename(os.path.dirname(f))] = ns / n / 1e3
     # calibration on the 1-GiB fp16 add
     cal = dict(fetch=2.0, write=1.0, source="guide default (FETCH_SIZE x2, WRITE_SIZE as reported)")
     for r in res:
@@ -142,6 +158,9 @@ def main():
             r["mfma_busy_frac"] = m["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (m["GRBM_GUI_ACTIVE"] / 8.0)
         if "SQ_ACTIVE_INST_VALU" in m and "GRBM_GUI_ACTIVE" in m and m["GRBM_GUI_ACTIVE"] > 0:
             r["valu_busy_frac"] = m["SQ_ACTIVE_INST_VALU"] * 4 / 1024.0 / (m["GRBM_GUI_ACTIVE"] / 8.0)
+        if "GRBM_GUI_ACTIVE" in m and r.get("mean_dispatch_us_by_pass"):
+            us = min(r["mean_dispatch_us_by_pass"].values())          # the least perturbed pass
+            r["effective_clock_ghz"] = (m["GRBM_GUI_ACTIVE"] / 8.0) / (us * 1e3)
     res.sort(key=lambda r: -r["total"].get("GRBM_GUI_ACTIVE", r["total"].get("FETCH_SIZE", 0)))
     outd = dict(calibration=cal, kernels=res)
     if fam:
