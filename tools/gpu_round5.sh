@@ -12,6 +12,8 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
+# the snapshot carries no .git: the caller writes the commit the tree was taken at into .anip_commit (recorded by the PMC summary)
+export ANIP_COMMIT=${ANIP_COMMIT:-$(cat .anip_commit 2>/dev/null)}
 for STEP in "$@"; do
   echo "=================== $STEP"
   case $STEP in
