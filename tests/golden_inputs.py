@@ -61,6 +61,7 @@ REAL_PIPE_CASES = {
     # BASELINE configs[3] at its OWN geometry: 512x512, L=150 -> 13 overlapping 16-frame windows per step (the last one
     # wrapping around the clip end), 1 DDIM step; stored frames sit in plain, overlapping and wrap-around windows
     "c4_1step": (512, 512, 150, 1, 3.5, 5, (0, 5, 12, 75, 146, 149)),
+    "c5_25step": (768, 768, 16, 25, 3.5, 3, (0, 5, 10, 15)),      # BASELINE configs[4] geometry with its WHOLE 25-step schedule
 }
 
 

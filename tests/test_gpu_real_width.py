@@ -10,7 +10,7 @@ the north star's criterion: PSNR >= 40 dB on the decoded frames for identical we
                       2 of the 16 frames; round 2's first GPU run did 2 steps x 16 frames: 46.4 dB, oracle 425 s)
   reference fixtures  tests/golden/real_pipeline_<case>.pt — outputs of the REFERENCE's own pipeline run on PyTorch-CPU fp32 in
                       the build container (oracle/make_golden_real_pipeline.py): C2 geometry at 4 DDIM steps, all 16 frames;
-                      C5 geometry (768x768, 96x96 latents) at 1 and 4 steps; C2 in full (25 steps); L=40 at real width (4 windows
+                      C5 geometry (768x768, 96x96 latents) at 1, 4 and all 25 steps; C2 in full (25 steps); L=40 at real width (4 windows
                       per step incl. the wrap-around one — the same windows at every step: the reference passes step 0 to its
                       context scheduler); C4 at its own geometry (512x512, L=150: 13 windows) at 1 step.  Only compared here —
                       no CPU oracle run on the GPU box.
@@ -186,6 +186,19 @@ def test_c5_768_four_steps_vs_reference_fixture(real_pipe):
     p, worst, lat_db = _report("C5 4 steps", vid, lats, gold, i)
     assert vid.shape == (1, 3, 16, 768, 768) and len(lats) == 4
     assert p >= PSNR_BAR and worst >= PSNR_BAR and min(lat_db) >= 40.0
+
+
+@torch.no_grad()
+def test_c5_768_full_25_step_schedule_vs_reference_fixture(real_pipe):
+    """BASELINE configs[4] geometry (768x768, L=16, CFG 3.5: 96x96 latents, 18 432 keys per conditional frame) with its WHOLE
+    25-step schedule against the reference's own pipeline on PyTorch-CPU fp32 (oracle/make_golden_real_pipeline.py c5_25step,
+    hours of CPU in the build container): 4 stored frames, the latent SNR after every one of the 25 steps"""
+    pipe, _ = real_pipe
+    vid, lats, gold, i = _fixture_case(pipe, "c5_25step")
+    p, worst, lat_db = _report("C5 25 steps", vid, lats, gold, i)
+    assert vid.shape == (1, 3, 16, 768, 768) and len(lats) == 25
+    assert p >= PSNR_BAR and worst >= PSNR_BAR and min(lat_db) >= 40.0
+    assert abs(float(vid.double().mean()) - float(gold["video_mean"])) < 2e-3
 
 
 @torch.no_grad()
