@@ -5,7 +5,7 @@
 #   fbench:<n>     tools/exp_fused_blocks.py (round 5's fused kernels against the launches they replace) -> fbench_<n>.jsonl
 #   kbench:<n> / abench:<n> / nbench:<n>   tools/bench_kernels.py gemm,conv / attn / norm -> *_<n>.jsonl
 #   qbench:<n>     short whole-clip bench (6 clips, no CPU baseline / roofline) under the current environment: whole-clip A/B pairs
-#   models / parity / alltests   model-level tests, fixture parity tests, the whole -m gpu suite
+#   models / parity / alltests / smoke   model-level tests, fixture parity tests, the whole -m gpu suite, __graft_entry__.smoke()
 #   bench / benchx / rocprof / pmc / pmck:<name>:<what>   as in tools/gpu_round4.sh
 TAG=${1:-r05a}; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$TAG
@@ -43,6 +43,8 @@ for STEP in "$@"; do
     N=${STEP#tbench:}
     ANIP_PIPE_TIMING=1 timeout 600 python bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-roofline > $OUT/tbench_$N.log 2>&1; echo "rc=$?"
     grep -iE "refnet|unet|vae|pose|clip|total" $OUT/tbench_$N.log | tail -n 6 | cut -c1-400 ;;
+  smoke)
+    timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; echo "rc=$?"; tail -n 2 $OUT/smoke.log | cut -c1-300 ;;
   models)
     timeout 1200 python -m pytest tests/test_gpu_models.py -m gpu -q -x > $OUT/models.log 2>&1; echo "rc=$?" >> $OUT/models.log
     grep -E "^FAILED|^ERROR|passed|failed|rc=" $OUT/models.log | tail -n 12 ;;
