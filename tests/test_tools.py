@@ -75,8 +75,34 @@ def test_pmc_summarize_knows_every_kernel_of_the_library():
     assert not unknown, f"tools/pmc_summarize.py: no kernel family for {unknown}"
 
 
+def test_pmc_summarize_effective_clock(tmp_path):
+    """GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / dispatch duration of the same CSV = the clock the kernel ran at; the
+    MFMA-busy fraction next to it (SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs) — VERDICT r4 item 8"""
+    kern = "_ZN12_GLOBAL__N_124temporal_qkv_attn_kernelILi4EEEvNS_6TbArgsE"
+    path = str(tmp_path / "pmck" / "pass1" / "p_counter_collection.csv")
+    os.makedirs(os.path.dirname(path))
+    cols = ["Correlation_Id", "Dispatch_Id", "Grid_Size", "Kernel_Name", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"]
+    with open(path, "w", newline="") as f:
+        w = csv.DictWriter(f, fieldnames=cols)
+        w.writeheader()
+        for d in range(2):                                   # two dispatches of 100 us at 2.0 GHz: 200 000 cycles per XCD
+            for xcd in range(8):
+                w.writerow(dict(Correlation_Id=d, Dispatch_Id=d, Grid_Size=262144, Kernel_Name=kern, Counter_Name="GRBM_GUI_ACTIVE",
+                                Counter_Value=200000.0, Start_Timestamp=1000 + d * 500000, End_Timestamp=1000 + d * 500000 + 100000))
+                w.writerow(dict(Correlation_Id=d, Dispatch_Id=d, Grid_Size=262144, Kernel_Name=kern, Counter_Name="SQ_VALU_MFMA_BUSY_CYCLES",
+                                Counter_Value=200000.0 * 128 * 0.36, Start_Timestamp=1000 + d * 500000, End_Timestamp=1000 + d * 500000 + 100000))
+    out = tmp_path / "s.json"
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "pmc_summarize.py"), str(tmp_path / "pmck"), str(out)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    k = json.load(open(out))["kernels"][0]
+    assert k["family"] == "gemm_kernel<false>" and k["launches"] == 2
+    assert abs(k["effective_clock_ghz"] - 2.0) < 1e-6 and abs(k["mfma_busy_frac"] - 0.36) < 1e-6
+    assert abs(k["mean_dispatch_us_by_pass"]["pass1"] - 100.0) < 1e-6
+
+
 def test_gpu_session_script_parses():
-    for script in ("tools/gpu_round4.sh",):
+    for script in ("tools/gpu_round4.sh", "tools/gpu_round5.sh"):
         subprocess.run(["bash", "-n", os.path.join(REPO, script)], check=True)
 
 
