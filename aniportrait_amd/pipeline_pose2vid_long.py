@@ -484,13 +484,10 @@ class Pose2VideoPipeline(_Base):
             sch.set_timesteps(num_inference_steps)
         timesteps = [int(t) for t in sch.timesteps.tolist()]
 
-        # CLIP image embedding -> one token per sample (uncond = zeros)
-        clip_image_embeds = self._clip_embeds(ref_image, device)
-        ehs = clip_image_embeds.unsqueeze(1)
-        if do_cfg:
-            ehs = torch.cat([torch.zeros_like(ehs), ehs], dim=0)
-        ehs = ehs.contiguous()
-        tm.mark("clip")
+        # (ANIP_NO_GRAPH=1: eager launches, for profilers whose counter collection cannot follow graph replays)
+        use_graph = (bool(use_graph) and device.type == "cuda" and ops._WORK is None and
+                     not os.environ.get("ANIP_NO_GRAPH"))
+        clip_dtype = next(self.image_encoder.parameters()).dtype      # = clip_image_embeds.dtype (prepare_latents draws in it)
 
         writer = ReferenceAttentionControl(self.reference_unet, do_classifier_free_guidance=do_cfg, mode="write",
                                            batch_size=1, fusion_blocks="full")
@@ -498,7 +495,7 @@ class Pose2VideoPipeline(_Base):
                                            batch_size=1, fusion_blocks="full")
 
         C = self.denoising_unet.in_channels
-        lat = self.prepare_latents(1, C, width, height, video_length, clip_image_embeds.dtype, device, generator,
+        lat = self.prepare_latents(1, C, width, height, video_length, clip_dtype, device, generator,
                                    latents)
         self.prepare_extra_step_kwargs(generator, eta)
         L = lat.shape[2]
@@ -511,8 +508,14 @@ class Pose2VideoPipeline(_Base):
         # reference image -> VAE latent mean * 0.18215
         vae = self._vae()
         ref_t = self.ref_image_processor.preprocess(ref_image, height=height, width=width).to(device)
-        ref_lat = vae.encode_mean_nhwc(ops.ncfhw_to_nhwc(ref_t.float().unsqueeze(2).contiguous()))
-        ref_lat = (ref_lat.float() * 0.18215).half()                 # (1, h, w, 4)
+        ref_x = ops.ncfhw_to_nhwc(ref_t.float().unsqueeze(2).contiguous())
+        if use_graph:     # ~70 launches on ONE image: host-bound when issued eagerly (5 ms per clip), a graph like the other once-per-clip networks
+            enc = self._aux_graph("vae_enc", vae, (tuple(ref_x.shape), str(device)),
+                                  lambda: _GraphedFn(lambda t: [vae.encode_mean_nhwc(t)], [ref_x]))
+            ref_lat = enc([ref_x])[0]
+        else:
+            ref_lat = vae.encode_mean_nhwc(ref_x)
+        ref_lat = (ref_lat.float() * 0.18215).half()                 # (1, h, w, 4): a new tensor (the graph's output buffer is reused)
         tm.mark("latents+vae_encode")
 
         # pose condition images (numpy path of VaeImageProcessor: values in [-1, 509], see image_processor.py)
@@ -530,11 +533,18 @@ class Pose2VideoPipeline(_Base):
         # (pose_guider.py: cross_attention_dim=None => no attn2): it is not preprocessed
         tm.mark("pose_preprocess")
 
+        # CLIP image embedding -> one token per sample (uncond = zeros).  Issued HERE (round 5), behind the VAE-encode graph and the
+        # pose upload: its host part (PIL resize + CLIPImageProcessor, ~4 ms) runs while the GPU works those off; nothing in front
+        # of this point needs it (prepare_latents only takes its dtype; the CLIP tower draws no random numbers)
+        clip_image_embeds = self._clip_embeds(ref_image, device)
+        ehs = clip_image_embeds.unsqueeze(1)
+        if do_cfg:
+            ehs = torch.cat([torch.zeros_like(ehs), ehs], dim=0)
+        ehs = ehs.contiguous()
+        tm.mark("clip")
+
         # ReferenceNet: one pass at t = 0 (pipeline_pose2vid_long.py:474-485); only the banks matter, so
         # the pass stops after the last bank write.  With a dp_group, rank 0 computes and broadcasts.
-        # (ANIP_NO_GRAPH=1: eager launches, for profilers whose counter collection cannot follow graph replays)
-        use_graph = (bool(use_graph) and device.type == "cuda" and ops._WORK is None and
-                     not os.environ.get("ANIP_NO_GRAPH"))
         windows = [list(c) for c in windows_fn(L, num_inference_steps)]
         # windows -> ranks by longest-processing-time over their frame counts (equal-length windows: round robin)
         my_windows = (D.shard_balanced([len(c) for c in windows], ws)[rank] if ws > 1 else list(range(len(windows))))
