@@ -3,7 +3,6 @@ API (src/models/unet_3d.py:27-29,399-410,582-590; src/models/unet_2d_condition.p
 HIP engine.  Same constructor config, same state-dict key names, same forward signatures and
 return types; the arithmetic runs in `engine.unet_forward` on libaniportrait_hip.so.
 """
-import os
 
 import torch
 

@@ -6,7 +6,6 @@ packing, the pipelines' window / CFG / DDIM orchestration) can be checked agains
 build container, which has no GPU.  It is never imported by the product: `install()` monkeypatches the
 module attributes for the duration of a test.  The kernels themselves are checked on the GPU
 (tests/test_hip_ops.py, tests/test_gpu_models.py)."""
-import math
 
 import torch
 import torch.nn.functional as F
