@@ -254,6 +254,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_small_kernel(const anip_gemm
           for (int e = 0; e < 8; ++e)
             if (e < nvalid) v[e] += rbp[e];
         }
+        if (p.act == 2) {   // quick-GELU x * sigmoid(1.702 x) (CLIP's MLP, transformers `QuickGELUActivation`), ahead of the residual
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = v[e] / (1.0f + __expf(-1.702f * v[e]));
+        }
         if (p.residual != nullptr) {
           const f16* rp = (const f16*)p.residual + (int64_t)m * p.ldr + ncol;
           if (nvalid == 8 && ((p.ldr & 7) == 0)) {
@@ -349,6 +353,7 @@ extern "C" int anip_gemm(const anip_gemm_params* pp, void* stream) {
                    "anip_gemm: bad two-source split K1=%d", p.K1);
     }
   }
+  ANIP_REQUIRE(p.act >= 0 && p.act <= 2, "anip_gemm: act=%d (0 none, 1 GEGLU, 2 quick-GELU)", p.act);
   if (p.trans_out)
     ANIP_REQUIRE(p.act == 0 && !p.out_f32 && !p.rowbias && !p.residual && p.batch == 1,
                  "anip_gemm: trans_out supports bias only");
@@ -365,7 +370,8 @@ extern "C" int anip_gemm(const anip_gemm_params* pp, void* stream) {
     // small / odd-shaped problems run on the 128x128 register-staged kernel below
     const int64_t extA = p.conv ? (int64_t)p.Nimg * p.Hin * p.Win * p.Cin : (int64_t)p.M * p.lda;
     int used = 0;
-    if (extA * 2 < 0xFFFF0000ll && (int64_t)p.N * p.ldw * 2 < 0xFFFF0000ll &&
+    // (act == 2, quick-GELU: the small-problem kernel's epilogue only — its one user is the CLIP tower's fc1 at M = 257 rows per image)
+    if (p.act != 2 && extA * 2 < 0xFFFF0000ll && (int64_t)p.N * p.ldw * 2 < 0xFFFF0000ll &&
         (!p.A2 || (int64_t)p.M * p.lda2 * 2 < 0xFFFF0000ll)) {
       used = anip_gemm2_try_splitk(p, (hipStream_t)stream);
       if (used == 0) used = anip_gemm2_try(p, (hipStream_t)stream);

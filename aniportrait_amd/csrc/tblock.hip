@@ -322,7 +322,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void rowgemm320_kernel(const RgArg
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int fr = lane & 15, fq = lane >> 4;
-  const int m0 = blockIdx.x * (32 * NW) + wave * 32;   // the wave's rows m0 .. m0 + 31 (M % 256 == 0)
+  const int m0 = blockIdx.x * (32 * NW) + wave * 32;   // the wave's rows m0 .. m0 + 31 (M % (32 * NW) == 0)
 
   const uint32_t lane_voff = (uint32_t)((lane >> 3) * C * 2 + (((lane & 7) ^ (lane >> 3)) << 4));
 #pragma unroll
@@ -486,7 +486,7 @@ extern "C" int anip_temporal_qkv_attention_supported(int F, int T, int C, int he
 }
 
 extern "C" int anip_rowgemm320_supported(int64_t M, int C, int64_t rows_per_frame) {
-  return (C == TB_C && M > 0 && (M % 128) == 0 && M * (int64_t)TB_C * 2 < (1ll << 40) && (rows_per_frame == 0 || rows_per_frame % 32 == 0))
+  return (C == TB_C && M > 0 && (M % (32 * TB_NW)) == 0 && M * (int64_t)TB_C * 2 < (1ll << 40) && (rows_per_frame == 0 || rows_per_frame % 32 == 0))
              ? 1 : 0;
 }
 

@@ -223,6 +223,7 @@ _FUSED_TEMPORAL = os.environ.get("ANIP_FUSED_TEMPORAL", "1") == "1"
 _FUSED_ROWS = os.environ.get("ANIP_FUSED_ROWS", "1") == "1"
 # unet_forward(cfg_shared_input=True): the CFG pair's identical prefix computed once.  ANIP_SHARE_CFG_PREFIX=0: both halves.
 _SHARE_CFG_PREFIX = os.environ.get("ANIP_SHARE_CFG_PREFIX", "1") == "1"
+_CHECK_CFG_PREFIX = os.environ.get("ANIP_CHECK_CFG_PREFIX", "0") == "1"
 
 
 def transformer_in(net, p, x):
@@ -236,6 +237,8 @@ def transformer_in(net, p, x):
         return ops.affine_linear320(x.reshape(N * T, C), sst, T, net.lin(p + ".proj_in.weight"), net.f32(p + ".proj_in.bias"))
     h = ops.groupnorm(x.reshape(N, T, C), net.f32(p + ".norm.weight"), net.f32(p + ".norm.bias"), 32, 1e-6, False)
     return ops.gemm(h.reshape(N * T, C), net.lin(p + ".proj_in.weight"), net.f32(p + ".proj_in.bias"))
+
+
 def feed_forward(net, p, h, norm):
     """LayerNorm `norm` -> diffusers FeedForward(geglu) -> + h (src/models/attention.py:361,436-445,
     src/models/motion_module.py:233-234,256-257): GEGLU fused in the first GEMM's epilogue."""
@@ -569,6 +572,11 @@ def unet_forward(net, cfg, x, b, f, t, ehs, attn2_cache, refs, with_motion, ref_
     p00 = "down_blocks.0.attentions.0"
     share = (cfg_shared_input and _SHARE_CFG_PREFIX and b == 2 and _DOWN_HAS_ATTN[0] and gn_frames == 1 and tap is None and
              not stop_after_last_bank and refs.get(p00) is not None and refs[p00].mode == "read" and ref_index is not None)
+    if share and _CHECK_CFG_PREFIX and not torch.cuda.is_current_stream_capturing():
+        # ANIP_CHECK_CFG_PREFIX=1 (debug): the caller's guarantee, verified — a host sync per call, never on by default
+        same = bool(torch.equal(x[:f], x[f:])) and bool(torch.equal(temb_all[0], temb_all[1]))
+        if not same:
+            raise ValueError("unet_forward(cfg_shared_input=True): the two CFG halves differ in x or in the time embedding")
     for i in range(nblk):
         for j in range(lpb):
             if share and i == 0 and j == 0:
@@ -742,3 +750,79 @@ def pose_guider_forward(net, stacks, x, training, use_ca):
             x = _pose_self_attn(net, f"cross_attn{i}", x)
         fea.append(x)
     return fea
+
+
+# ----------------------------------------------------------------------------------------------------
+# CLIP vision tower (the reference image's embedding, once per clip)
+# ----------------------------------------------------------------------------------------------------
+
+def clip_patch_weight(net, Kp):
+    """patch_embedding Conv2d(3, C, k = s = patch, bias=False) as a GEMM matrix fp16 [C][Kp]: (c, ky, kx)-ordered columns,
+    zero-padded to the Kp columns of `clip_patches`"""
+    k = ("clippatch", int(Kp))
+    if k not in net.t:
+        w = net._raw("vision_model.embeddings.patch_embedding.weight")
+        w = w.reshape(w.shape[0], -1).to(net.device, F16)
+        wp = torch.zeros((w.shape[0], Kp), dtype=F16, device=net.device)
+        wp[:, :w.shape[1]] = w
+        net.t[k] = wp
+    return net.t[k]
+
+
+def clip_token_table(net):
+    """fp16 [1 + P][C]: row 0 = class_embedding + position_embedding[0], row 1 + i = position_embedding[1 + i] — the residual of
+    the patch GEMM (the class token's GEMM row is all zeros)"""
+    k = ("cliptok",)
+    if k not in net.t:
+        pos = net._raw("vision_model.embeddings.position_embedding.weight").to(net.device, F32).clone()
+        pos[0] += net._raw("vision_model.embeddings.class_embedding").to(net.device, F32)
+        net.t[k] = pos.to(F16).contiguous()
+    return net.t[k]
+
+
+def clip_vision_forward(net, cfg, patches):
+    """`CLIPVisionModelWithProjection(pixel_values).image_embeds` of transformers (the call of
+    src/pipelines/pipeline_pose2vid_long.py:379-385) on the HIP kernels: ViT with a class token, pre-LayerNorm, L x [LN ->
+    q | k | v (+ bias) -> softmax attention over the 1 + P tokens -> out_proj + residual -> LN -> fc1 + quick-GELU -> fc2 +
+    residual], post-LayerNorm of the class token, bias-free visual projection.
+
+    patches (B * (1 + P), Kp) fp16: per image one all-zero row (the class token's slot) followed by its P im2col'd patches in
+    row-major patch order, each (c, ky, kx)-ordered and zero-padded to Kp (`clip_vision.patch_rows`, built on the host from the
+    `CLIPImageProcessor` output, which lives there anyway).  cfg: hidden_size, num_attention_heads, num_hidden_layers,
+    layer_norm_eps.  Returns (B, projection_dim) fp16."""
+    C, heads, eps = cfg["hidden_size"], cfg["num_attention_heads"], cfg["layer_norm_eps"]
+    d = C // heads
+    tok = clip_token_table(net)
+    T = tok.shape[0]
+    M = patches.shape[0]
+    B = M // T
+    assert B * T == M, f"patch rows {M} are not a multiple of the {T} tokens per image"
+    wpe = clip_patch_weight(net, patches.shape[1])
+    if B == 1:
+        h = ops.gemm(patches, wpe, residual=tok)
+    else:
+        h = torch.empty((M, C), dtype=F16, device=patches.device)
+        for b_ in range(B):
+            ops.gemm(patches[b_ * T:(b_ + 1) * T], wpe, residual=tok, out=h[b_ * T:(b_ + 1) * T])
+    vm = "vision_model."
+    h = ops.layernorm(h, net.f32(vm + "pre_layrnorm.weight"), net.f32(vm + "pre_layrnorm.bias"), eps)
+    qa = ops.attn_q_alpha(d)
+    Mp = (M + 7) // 8 * 8           # V^T row pitch: 16-B aligned rows; ONE buffer for all layers, its pad columns stay zero
+    vt = torch.zeros((C, Mp), dtype=F16, device=patches.device)
+    for i in range(cfg["num_hidden_layers"]):
+        p = f"{vm}encoder.layers.{i}."
+        a = p + "self_attn."
+        nh = ops.layernorm(h, net.f32(p + "layer_norm1.weight"), net.f32(p + "layer_norm1.bias"), eps)
+        # q carries d^-1/2 log2(e) (weights through the GEMM's alpha, the bias pre-multiplied): the attention kernel
+        # exponentiates in base 2; k head-major, v transposed — the layouts of the UNets' reference attention
+        q = ops.gemm(nh, net.lin(a + "q_proj.weight"), net.scaled_f32(a + "q_proj.bias", qa), alpha=qa)
+        k = ops.gemm(nh, net.lin(a + "k_proj.weight"), net.f32(a + "k_proj.bias"), head_dim=d)
+        ops.gemm(nh, net.lin(a + "v_proj.weight"), net.f32(a + "v_proj.bias"), trans_out=True, out=vt, ldo=Mp)
+        o = ops.ref_attention(q, C, k, d, vt, Mp, B, T, heads, d, k_head_stride=M * d, q_log2_scaled=True)
+        h = ops.gemm(o, net.lin(a + "out_proj.weight"), net.f32(a + "out_proj.bias"), residual=h)
+        nh = ops.layernorm(h, net.f32(p + "layer_norm2.weight"), net.f32(p + "layer_norm2.bias"), eps)
+        g = ops.gemm(nh, net.lin(p + "mlp.fc1.weight"), net.f32(p + "mlp.fc1.bias"), act=2)
+        h = ops.gemm(g, net.lin(p + "mlp.fc2.weight"), net.f32(p + "mlp.fc2.bias"), residual=h)
+    pooled = h[:1] if B == 1 else h.reshape(B, T, C)[:, 0].contiguous()
+    pooled = ops.layernorm(pooled, net.f32(vm + "post_layernorm.weight"), net.f32(vm + "post_layernorm.bias"), eps)
+    return ops.gemm(pooled, net.lin("visual_projection.weight"))

@@ -556,6 +556,15 @@ def ref_attention(q, ldq, k, ldk, vt, ldvt, n_frames, T, heads, d, kref=None, ld
     (heads, tokens, d)): ldk = d and k_head_stride = tokens * d.  q_log2_scaled: q already carries scale * log2(e)
     (ANIP_ATTN_Q_LOG2_SCALED: gemm(..., alpha=attn_q_alpha(d)) of the to_q projection)."""
     lib = L.load()
+    frame_mod = int(frame_mod)
+    if not 0 <= frame_mod < 32768:      # packed into bits 16.. of a C int: a larger value would wrap silently
+        raise ValueError(f"ref_attention: frame_mod must be in [0, 32767], got {frame_mod}")
+    held = frame_mod if frame_mod else n_frames
+    if frame_mod and n_frames % frame_mod:
+        raise ValueError(f"ref_attention: n_frames ({n_frames}) must be a multiple of frame_mod ({frame_mod})")
+    if q.numel() < held * T * heads * d or k.numel() < held * T * heads * d or vt.numel() < held * T * heads * d:
+        raise ValueError(f"ref_attention: q / k / vt must hold {held} frames of {T} tokens x {heads * d} channels "
+                         f"(q {tuple(q.shape)}, k {tuple(k.shape)}, vt {tuple(vt.shape)})")
     _work(K_REF_ATTN, 4 * T * T * heads * d * (n_frames + (n_ref_frames if ref_index is not None else 0)),
           f"Nf{n_frames} T{T} h{heads} d{d} ref{n_ref_frames if ref_index is not None else 0}",
           2 * heads * d * (4 * n_frames * T + (2 * kref.numel() // (heads * d) if kref is not None else 0)))

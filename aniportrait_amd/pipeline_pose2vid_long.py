@@ -20,6 +20,7 @@ Extra keyword arguments (all optional, reference callers never pass them):
   async_output=    True: `.videos` is a `PendingVideo`; the D2H copy runs on a side stream into pinned memory and
                    `.result()` waits for it — lets a caller start the next clip while the frames drain.
 """
+import gc
 import inspect
 import math
 import os
@@ -32,6 +33,7 @@ import torch
 from . import distributed as D
 from . import engine
 from . import hipops as ops
+from . import hostcfg
 from .autoencoder_kl import AutoencoderKL
 from .context import get_context_scheduler
 from .image_processor import VaeImageProcessor, randn_tensor
@@ -39,17 +41,24 @@ from .modeling import BaseOutput
 from .mutual_self_attention import ReferenceAttentionControl
 
 
+_GC_CONTROL = os.environ.get("ANIP_GC_CONTROL", "1") == "1"
+
+
 class _StageTimer:
     """ANIP_PIPE_TIMING=1: synchronised wall time per pipeline stage, printed at the end of the call."""
 
     def __init__(self):
-        self.on = bool(os.environ.get("ANIP_PIPE_TIMING"))
+        # ANIP_PIPE_TIMING=host: the same marks WITHOUT the synchronize — host time per stage as the un-instrumented call sees it
+        mode = os.environ.get("ANIP_PIPE_TIMING")
+        self.on = bool(mode)
+        self.sync = mode != "host"
         self.t0 = self.last = time.perf_counter()
         self.rows = []
 
     def mark(self, name):
         if self.on:
-            torch.cuda.synchronize()
+            if self.sync:
+                torch.cuda.synchronize()
             now = time.perf_counter()
             self.rows.append((name, (now - self.last) * 1e3))
             self.last = now
@@ -272,6 +281,7 @@ class Pose2VideoPipeline(_Base):
         self.cond_image_processor = VaeImageProcessor(vae_scale_factor=self.vae_scale_factor, do_convert_rgb=True,
                                                       do_normalize=True)
         self._hip_vae = None
+        hostcfg.bound_host_threads()    # a 128-thread intra-op pool under a 16-CPU cgroup quota freezes the process (hostcfg.py)
 
     @property
     def _execution_device(self):
@@ -348,30 +358,45 @@ class Pose2VideoPipeline(_Base):
         raise NotImplementedError("interpolation_factor >= 2 is dead at the reference's defaults (SURVEY.md §2.1 #14)")
 
     # -- stages ---------------------------------------------------------------------------------------
+    def _hip_clip(self):
+        """the HIP form of `self.image_encoder` (a transformers CLIPVisionModelWithProjection, adopted once via its config +
+        state-dict like a foreign AutoencoderKL; re-adopted when the module is replaced, moved or re-typed)"""
+        src = self.image_encoder
+        p = next(src.parameters())
+        tag = (id(src), str(p.device), p.dtype, p.data_ptr(), p._version)
+        cur = self.__dict__.get("_hip_clip_state")
+        if cur is None or cur[0] != tag:
+            from .clip_vision import CLIPVisionHip
+            cur = self.__dict__["_hip_clip_state"] = (tag, CLIPVisionHip.from_module(src))
+        return cur[1]
+
     def _clip_embeds(self, ref_image, device):
-        """CLIP image embedding of the reference image (pipeline_pose2vid_long.py:379-385).  The encoder is the transformers
-        module as given (outside the HIP scope); on the GPU its forward — a few hundred small launches, 9-10 ms of host-bound
-        launching per clip next to a 1.27 s clip — is captured once per encoder / input shape into a hipGraph and replayed
-        (same kernels, same result).  A module that cannot be captured (capture error) runs eagerly from then on."""
+        """CLIP image embedding of the reference image (pipeline_pose2vid_long.py:379-385).  Round 6: the tower runs on the HIP
+        kernels (`engine.clip_vision_forward`; `clip_vision.CLIPVisionHip` adopts the transformers module's weights) — the last
+        torch / rocBLAS / AOTriton kernels inside `pipe(...)` are gone.  The 224 x 224 resize and the CLIPImageProcessor stay on
+        the host (PIL / numpy, as in the reference), where the im2col of the 14 x 14 patches is done as well, so ONE (257, 640)
+        fp16 matrix is uploaded; the ~220 launches of the forward are a hipGraph like the other once-per-clip networks.
+        ANIP_CLIP_TORCH=1: the module as given, eagerly (A/B measurements, foreign towers)."""
+        tm = getattr(self, "_tm", None)
         clip_image = self.clip_image_processor.preprocess(ref_image.resize((224, 224)), return_tensors="pt").pixel_values
+        if tm is not None:
+            tm.mark("clip.preprocess")
         enc = self.image_encoder
         p = next(enc.parameters())
-        x = clip_image.to(p.device, dtype=p.dtype)
-        st = self.__dict__.setdefault("_clip_graph", {})
-        if (p.device.type == "cuda" and not os.environ.get("ANIP_NO_GRAPH") and not st.get("failed")
+        if os.environ.get("ANIP_CLIP_TORCH") == "1":
+            return enc(clip_image.to(p.device, dtype=p.dtype)).image_embeds.to(device)
+        hip = self._hip_clip()
+        rows = hip.patch_rows(clip_image.float()).to(hip.device)
+        if tm is not None:
+            tm.mark("clip.h2d")
+        if (hip.device.type == "cuda" and ops._WORK is None and not os.environ.get("ANIP_NO_GRAPH")
                 and not torch.cuda.is_current_stream_capturing()):
-            key = (id(enc), tuple(x.shape), x.dtype, str(p.device), p.data_ptr())
-            if st.get("key") != key:
-                st.clear()
-                st["key"] = key
-                st["fn"] = _GraphedFn(lambda px: [enc(px).image_embeds], [x])
-            try:
-                return st["fn"]([x])[0].clone().to(device)
-            except RuntimeError:
-                st.clear()
-                st["failed"] = True
-                torch.cuda.synchronize(p.device)
-        return enc(x).image_embeds.to(device)
+            g = self._aux_graph("clip", hip, (tuple(rows.shape), str(hip.device)),
+                                lambda: _GraphedFn(lambda r: [hip.image_embeds_from_rows(r)], [rows]))
+            out = g([rows])[0].clone()          # the graph's output buffer is reused by the next clip
+        else:
+            out = hip.image_embeds_from_rows(rows)
+        return out.to(dtype=p.dtype).to(device)
 
     def _fused_step_coefficients(self, t):
         sch = self.scheduler
@@ -409,7 +434,6 @@ class Pose2VideoPipeline(_Base):
         self.__dict__["_runners"] = OrderedDict()
         self.__dict__.pop("_runner_tag", None)
         self.__dict__["_aux_graphs"] = {}
-        self.__dict__["_clip_graph"] = {}
         for name in ("denoising_unet", "reference_unet"):
             drop = getattr(getattr(self, name, None), "drop_reference_pools", None)
             if drop is not None:
@@ -461,14 +485,32 @@ class Pose2VideoPipeline(_Base):
             raise RuntimeError("Pose2VideoPipeline: the denoising path only runs on an MI355X (HIP kernels); "
                                "call pipe.to('cuda') — there is no CPU fallback")
 
+    def _run(self, *args, **kwargs):
+        """`_run_clip` with the interpreter's cyclic garbage collector under control (ANIP_GC_CONTROL=0: left alone).  A full
+        (generation-2) collection of a process that holds five networks, their packed weights and the captured graphs takes
+        45-85 ms, and the interpreter starts one wherever the allocation counters happen to cross their thresholds — round 6
+        measured it as ONE host-side stall in roughly every second clip, inside whichever host-bound stage was running (CLIP
+        preprocessing, pose upload, VAE encode, the first graph replay), with the GPU idle behind it: per-clip wall times were
+        bimodal, 1 237 ms / 1 300 ms (profiles/r06/b_*).  So: automatic collection is switched off while the host is on the
+        critical path, and ONE full collection per clip runs where the host has nothing to do — behind the last launch of
+        the clip, with the GPU's queue holding the work of the remaining steps and the VAE decode."""
+        managed = _GC_CONTROL and gc.isenabled()
+        if managed:
+            gc.disable()
+        try:
+            return self._run_clip(*args, **kwargs)
+        finally:
+            if managed:
+                gc.enable()
+
     @torch.no_grad()
-    def _run(self, ref_image, pose_images, ref_pose_image, width, height, video_length, num_inference_steps,
-             guidance_scale, num_images_per_prompt, eta, generator, output_type, return_dict, callback, callback_steps,
-             windows_fn, latents=None, dp_group=None, decode_chunk=16, return_latents=False, use_graph=True,
-             async_output=False):
+    def _run_clip(self, ref_image, pose_images, ref_pose_image, width, height, video_length, num_inference_steps,
+                  guidance_scale, num_images_per_prompt, eta, generator, output_type, return_dict, callback, callback_steps,
+                  windows_fn, latents=None, dp_group=None, decode_chunk=16, return_latents=False, use_graph=True,
+                  async_output=False):
         device = self._execution_device
         self._require_gpu(device)
-        tm = _StageTimer()
+        tm = self.__dict__["_tm"] = _StageTimer()
         if num_images_per_prompt != 1:
             raise NotImplementedError("num_images_per_prompt != 1")
         if eta != 0.0:
@@ -507,7 +549,11 @@ class Pose2VideoPipeline(_Base):
 
         # reference image -> VAE latent mean * 0.18215
         vae = self._vae()
-        ref_t = self.ref_image_processor.preprocess(ref_image, height=height, width=width).to(device)
+        tm.mark("latents")
+        ref_t = self.ref_image_processor.preprocess(ref_image, height=height, width=width)
+        tm.mark("ref.preprocess")
+        ref_t = ref_t.to(device)
+        tm.mark("ref.h2d")
         ref_x = ops.ncfhw_to_nhwc(ref_t.float().unsqueeze(2).contiguous())
         if use_graph:     # ~70 launches on ONE image: host-bound when issued eagerly (5 ms per clip), a graph like the other once-per-clip networks
             enc = self._aux_graph("vae_enc", vae, (tuple(ref_x.shape), str(device)),
@@ -524,7 +570,9 @@ class Pose2VideoPipeline(_Base):
         if all(isinstance(p, np.ndarray) and p.dtype == np.uint8 and p.shape == (hp, wp, 3) for p in pose_images):
             # renderings already at the target size (scripts/pose2vid.py:158 resizes them): upload the bytes once;
             # (L, H, W, 3) uint8 is the channels-last frame batch, 2 v - 1 is applied on the device
-            pose_nhwc = ops.u8_to_f16(torch.from_numpy(np.stack(pose_images)).to(device), 2.0, -1.0)
+            stacked = torch.from_numpy(np.stack(pose_images))
+            tm.mark("pose.stack")
+            pose_nhwc = ops.u8_to_f16(stacked.to(device), 2.0, -1.0)
         else:
             pose = torch.cat([self.cond_image_processor.preprocess(p, height=height, width=width).unsqueeze(2)
                               for p in pose_images], dim=2).to(device=device, dtype=pg.dtype)
@@ -606,6 +654,7 @@ class Pose2VideoPipeline(_Base):
         temb_table = torch.stack([engine.timestep_sinusoid(t, S, ucfg["block_out_channels"][0], "cpu",
                                                            ucfg.get("flip_sin_to_cos", True), ucfg.get("freq_shift", 0))
                                   for t in timesteps]).to(device)
+        tm.mark("temb_table")
         runners = self._get_runners()
         clip_runners = {}
 
@@ -667,6 +716,8 @@ class Pose2VideoPipeline(_Base):
             video = None if frames is None else (frames if u8 else frames.permute(1, 0, 2, 3).unsqueeze(0))
         else:
             video = self._decode_nhwc(z, 1, decode_chunk, u8)
+        if _GC_CONTROL and not gc.isenabled():
+            gc.collect()        # the host's idle point: everything of this clip is queued (see _run)
         if video is None:
             return None
         tm.mark("vae_decode")
@@ -680,7 +731,9 @@ class Pose2VideoPipeline(_Base):
         if async_output:
             images = self._to_host_async(video, finish)
         else:
-            images = finish(video.cpu())
+            host = video.cpu()
+            tm.mark("d2h")
+            images = finish(host)
         tm.mark("d2h+float")
         tm.report()
         if not return_dict:

@@ -163,19 +163,19 @@ def extra_configs(pipe, seed=0):
 
 CPU_BASELINE_THREADS = 64     # fixed (min with the schedulable cores): the oracle's conv / linear kernels stop scaling
 #                               there on the GPU box's host (round-2 scan: 64 -> 1.3 ms, 256 -> 500 ms per 320-ch 3x3 conv)
-CPU_BASELINE_STEP_LIMIT_S = 420   # headline-geometry sample: no second DDIM step if the first (with the fixed part) took longer
 CPU_BASELINE_STEPS = 3        # DDIM steps of the fixed sample (BASELINE configs[0] has 10)
 
 
-def cpu_baseline(size=512, frames=16, c1=(256, 4, None)):
+def cpu_baseline(size=512, frames=16, c1=(256, 4, None), steps_timed=1, threads=None):
     """The CPU path timed beside the GPU one: the oracle (oracle/ref_torch.py, a restatement of the
     reference's PyTorch-CPU fp32 pipeline, kind "port") on a FIXED thread count (min(64, schedulable cores); no per-run
     picker) and on the HEADLINE geometry — 512x512, L = 16, CFG 3.5, real SD-1.5 / sd-vae-ft-mse widths — as SURVEY.md
-    §8(d) prescribes: VAE encode + ReferenceNet + PoseGuider + 2 DDIM steps (two UNet3D calls on the 32-frame CFG batch,
-    reference attention over 8192 keys) + 1 VAE frame decode, every part timed by itself, extrapolated LINEARLY to the
-    25-step, 16-frame clip: fixed + 25 x step + 16 x frame (`value`; labelled "extrapolated").  The second step is
-    skipped if the first needed more than CPU_BASELINE_STEP_LIMIT_S seconds (a slow host must not push the run past the
-    driver's timeout); the figure then rests on one step and says so.  The round-1..4 sample — BASELINE configs[0]'s
+    §8(d) prescribes: VAE encode + ReferenceNet + PoseGuider (the once-per-clip part: everything in front of the first UNet3D
+    call) + `steps_timed` UNet3D calls on the 32-frame CFG batch (reference attention over 8192 keys; each call stamped right
+    before and right after, so a step never contains the once-per-clip part — round 5 subtracted it and over-estimated a step
+    whenever only one was run) + 1 VAE frame decode, extrapolated LINEARLY to the 25-step, 16-frame clip: fixed + 25 x step +
+    16 x frame (`value`; labelled "extrapolated").  One call is timed by default (round 5 ran two: 179 s each on the GPU box's
+    host, equal to 0.1 %; the leg was 355 s of a 486-s bench run).  The round-1..4 sample — BASELINE configs[0]'s
     geometry (256x256, L = 4) at 3 DDIM steps, run to completion and scaled by algorithmic FLOPs — is kept as the second
     field `c1_sample`: conv efficiency on the CPU differs between the two geometries, which is why the headline one is
     now measured directly.  (size / frames / c1: tests/test_tools.py runs the same code at toy sizes.)"""
@@ -184,11 +184,13 @@ def cpu_baseline(size=512, frames=16, c1=(256, 4, None)):
     from aniportrait_amd.synthetic import synth_latents, synth_pose_frames, synth_ref_image
     from oracle import ref_torch as O
 
+    from aniportrait_amd import hostcfg
     try:
         ncpu = len(os.sched_getaffinity(0))
     except AttributeError:
         ncpu = os.cpu_count()
-    threads = max(1, min(CPU_BASELINE_THREADS, ncpu))
+    quota = hostcfg.cpu_quota()
+    threads = max(1, min(CPU_BASELINE_THREADS, ncpu)) if threads is None else int(threads)
     torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(0)
 
@@ -216,16 +218,20 @@ def cpu_baseline(size=512, frames=16, c1=(256, 4, None)):
     class _Stop(Exception):
         pass
 
-    def run(H, W, L, steps, marks=None, limit=None, latents_only=False):
+    def run(H, W, L, steps, begins=None, ends=None, stop_after=None, latents_only=False):
+        def before_unet():
+            if begins is not None:
+                begins.append(time.time())
+
         def progress():
-            if marks is not None:
-                marks.append(time.time())
-                if limit is not None and len(marks) == 2 and marks[1] - marks[0] > limit:
+            if ends is not None:
+                ends.append(time.time())
+                if stop_after is not None and len(ends) >= stop_after:
                     raise _Stop()
         with torch.no_grad():
             return O.pose2vid(sds, cfgs, clip, synth_ref_image(H, W), list(synth_pose_frames(L, H, W)),
                               synth_pose_frames(1, H, W, 999)[0], W, H, L, steps, 3.5, synth_latents(L, H // 8, W // 8), long=True,
-                              return_latents=latents_only, progress=progress)
+                              return_latents=latents_only, progress=progress, before_unet=before_unet)
 
     run(64, 64, 2, 1)                       # untimed: thread pool, allocator, oneDNN primitive caches
     # ---- the round-1..4 sample: BASELINE configs[0] geometry, scaled by FLOPs -----------------------------------------------
@@ -239,22 +245,20 @@ def cpu_baseline(size=512, frames=16, c1=(256, 4, None)):
               what=f"{c1_size}x{c1_size}, L={c1_frames}, CFG 3.5, real widths, {c1_steps} of 10 DDIM steps run in full, scaled by algorithmic "
                    f"FLOPs ({tf_s:.2f} -> {tf_c2:.1f} TFLOP)")
     # ---- the headline geometry, measured: fixed part + DDIM steps + one VAE frame ---------------------------------------------
-    marks = [time.time()]
+    # One UNet3D call is timed by itself (stamps right before and right after it: `before_unet` / `progress` of
+    # oracle.pose2vid); everything in front of the first stamp — VAE encode, ReferenceNet, PoseGuider, pre-processing — is the
+    # once-per-clip part.  `steps_timed` calls are run (default 1: a call is ~3 min on the GPU box's host), then the run stops.
+    t_start = time.time()
+    begins, ends = [], []
     lat = None
     try:
-        lat = run(size, size, frames, 2, marks=marks, limit=CPU_BASELINE_STEP_LIMIT_S, latents_only=True)
+        lat = run(size, size, frames, steps_timed, begins=begins, ends=ends, stop_after=steps_timed, latents_only=True)
     except _Stop:
         pass
     t_end = time.time()
-    # marks: [start, after UNet3D call 1, after UNet3D call 2]; the DDIM update behind a call is < 1 ms
-    if len(marks) >= 3:
-        step_s = marks[2] - marks[1]
-        fixed_s = max(0.0, (marks[1] - marks[0]) - step_s)
-        n_steps = 2
-    else:
-        step_s = marks[1] - marks[0]        # one step only: includes VAE encode + ReferenceNet + PoseGuider (over-estimates a step)
-        fixed_s = 0.0
-        n_steps = 1
+    n_steps = len(ends)
+    step_s = sum(e - b for b, e in zip(begins, ends)) / n_steps
+    fixed_s = begins[0] - t_start
     if lat is None:
         lat = synth_latents(frames, size // 8, size // 8)
     t1 = time.time()
@@ -263,16 +267,16 @@ def cpu_baseline(size=512, frames=16, c1=(256, 4, None)):
     frame_s = time.time() - t1
     t_clip = fixed_s + 25 * step_s + frames * frame_s
     meas_tf = n_steps * TF_UNET.get(size, 0.0) + TF_REFNET.get(size, 0.0) + TF_VAE_FRAME.get(size, 0.0)
-    meas_s = (t_end - marks[0]) + frame_s
+    meas_s = (t_end - t_start) + frame_s
     return dict(value=frames / t_clip, unit="frames/s", cores=threads, kind="port", extrapolated=True, schedulable_cores=ncpu,
+                cgroup_cpu_quota=quota,
                 sample_seconds=meas_s, sample_tflop=meas_tf, cpu_tflops=meas_tf / meas_s,
                 fixed_seconds=fixed_s, step_seconds=step_s, vae_frame_seconds=frame_s, ddim_steps_timed=n_steps, c1_sample=c1,
                 sample=f"oracle/ref_torch.py fp32 on {threads} torch threads (fixed; {ncpu} schedulable cores) at the HEADLINE "
                        f"geometry {size}x{size}, L={frames}, CFG 3.5, real widths: VAE encode + ReferenceNet + PoseGuider {fixed_s:.1f} s, "
                        f"{n_steps} DDIM step(s) = UNet3D on the {2 * frames}-frame CFG batch {step_s:.1f} s each, 1 VAE frame decode "
                        f"{frame_s:.1f} s ({meas_tf:.1f} TFLOP in {meas_s:.0f} s = {meas_tf / meas_s:.3f} TFLOP/s); extrapolated "
-                       f"linearly to 25 steps and {frames} frames: {t_clip:.0f} s per clip"
-                       + ("" if n_steps == 2 else " (second step skipped: the first exceeded the time limit; the step time includes the fixed part)"))
+                       f"linearly to 25 steps and {frames} frames: {t_clip:.0f} s per clip")
 
 
 def main():
@@ -285,8 +289,11 @@ def main():
     ap.add_argument("--ddim-steps", type=int, default=25)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--extra-configs", action="store_true",
-                    help="after the headline run also time BASELINE configs[3] (L=150, 13 windows) and configs[4] (768x768)")
+    ap.add_argument("--extra-configs", dest="extra_configs", action="store_true", default=None,
+                    help="after the headline run also time BASELINE configs[3] (L=150, 13 windows) and configs[4] (768x768) on this "
+                         "GPU (about 40 s: one C4 clip, a warm-up and one C5 clip).  Default since round 6: ON for --gpus 1 at the "
+                         "headline geometry, so the driver's own bench line witnesses C4 and C5")
+    ap.add_argument("--no-extra-configs", dest="extra_configs", action="store_false")
     ap.add_argument("--table-dir", default=None, help="also write the per-kernel / per-shape table here")
     ap.add_argument("--long-clip", action="store_true",
                     help="BASELINE configs[3] instead of the headline: ONE 150-frame clip per step (13 context windows per DDIM "
@@ -312,8 +319,10 @@ def main():
         torch.cuda.set_device(0)
     n_gpus = world
     assert a.gpus == n_gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-    if world > 1:  # the per-clip host work (PIL resize, CLIP preprocessing) is tiny: do not oversubscribe the host cores
-        torch.set_num_threads(max(1, (os.cpu_count() or 8) // (2 * world)))
+    # the per-clip host work (PIL resize, CLIP preprocessing, dtype conversions) is tiny and the box's container has a CPU
+    # quota (16 CPUs on the MI355X boxes): a pool sized by the visible cores gets the process throttled (aniportrait_amd/hostcfg.py)
+    from aniportrait_amd import hostcfg
+    hostcfg.bound_host_threads(limit=max(1, min(8, hostcfg.usable_cpus() // (2 * world))), force=True)
     device = torch.device("cuda", local_rank if world > 1 else 0)
 
     H = W = a.size
@@ -339,8 +348,13 @@ def main():
     barrier()
     t0 = time.perf_counter()
     vids = []
+    clip_ms = []                # wall time of every timed call (the call returns host frames, so it is synchronous): shows a
+    tc = t0                     # host-side hiccup as ONE slow clip instead of a lower mean
     for i in range(a.steps):
         vids.append((i % 2, run_clip(pipe, inputs[i % 2], H, W, L, a.ddim_steps, 3.5, **clip_kw)))
+        tn = time.perf_counter()
+        clip_ms.append((tn - tc) * 1e3)
+        tc = tn
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -383,7 +397,7 @@ def main():
             "metric": ("generated frames/sec, 512x512 L=150 25-step pose2vid long clip" if a.long_clip else
                        "generated frames/sec, 512x512 L=16 25-step pose2vid"),
             "value": fps, "unit": "frames/s", "n_gpus": n_gpus, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "strong" if a.long_clip else "weak",
+            "ms_per_step": elapsed / a.steps * 1e3, "per_clip_ms": [round(m, 1) for m in clip_ms], "higher_is_better": True, "scaling": "strong" if a.long_clip else "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": ({"workload": f"pose2vid {H}x{W}, L={L} (13 context windows of 16 frames per DDIM step), {a.ddim_steps} "
                                     "DDIM steps, CFG=3.5, fp16, ONE clip per step sharded over the GPUs (BASELINE.json configs[3])",
@@ -472,6 +486,8 @@ def main():
                 os.makedirs(d, exist_ok=True)
                 with open(os.path.join(d, "bench_kernels_table.json"), "w") as f:
                     json.dump(dump, f, indent=1)
+        if a.extra_configs is None:
+            a.extra_configs = bool(n_gpus == 1 and is_c2 and not a.long_clip)
         if n_gpus == 1 and a.extra_configs:
             out["extra_configs"] = extra_configs(pipe)
         if n_gpus == 1 and not a.no_cpu_baseline:

@@ -83,7 +83,10 @@ typedef struct anip_gemm_params {
                                             length-1 CLIP cross-attention (mutual_self_attention.py:191-205) */
   const void* residual; int64_t ldr;     /* fp16 [M][N] added last, or NULL */
   int act;                               /* 0 none; 1 GEGLU: W/bias rows packed per 32 as [16 x h | 16 x gate]
-                                            (N % 128 == 0), out[M][N/2] = h * gelu_erf(gate) */
+                                            (N % 128 == 0), out[M][N/2] = h * gelu_erf(gate);
+                                            2 quick-GELU x * sigmoid(1.702 x) on (alpha acc + bias + rowbias), ahead of the
+                                            residual: fc1 of the CLIP vision tower's MLP (transformers QuickGELUActivation,
+                                            reached from pipeline_pose2vid_long.py:379-385) */
   int batch; int64_t strideA, strideW, strideO; /* batched GEMM over blockIdx.y (elements) */
   /* implicit 3x3 convolution (conv != 0): A is an NHWC image batch, M = Nimg*Hout*Wout, K = 9*Cin.
    * conv = 1: tap-major K, W = [Cout][3][3][Cin].  conv = 2 (Cin % 64 == 0): channel-block-major K,

@@ -499,7 +499,7 @@ def preprocess_np(arr, height, width):
 @torch.no_grad()
 def pose2vid(sds, cfgs, clip_embeds, ref_image, pose_images, ref_pose_image, width, height, video_length,
              num_inference_steps, guidance_scale, latents, context_frames=16, context_stride=1,
-             context_overlap=4, long=True, return_latents=False, progress=None):
+             context_overlap=4, long=True, return_latents=False, progress=None, before_unet=None):
     """Pose2VideoPipeline.__call__ restated (pipeline_pose2vid_long.py:339-584; short variant
     pipeline_pose2vid.py:286-468 when long=False).
 
@@ -529,6 +529,8 @@ def pose2vid(sds, cfgs, clip_embeds, ref_image, pose_images, ref_pose_image, wid
             lat_in = latents[:, :, c].repeat(nb, 1, 1, 1, 1)
             if wi not in pose_cache:  # the reference recomputes this every step; it is t-independent
                 pose_cache[wi] = pose_guider(sds["pose_guider"], pose[:, :, c].repeat(nb, 1, 1, 1, 1), ref_pose)
+            if before_unet is not None:     # bench.py's cpu_baseline: separates the once-per-clip part from a UNet3D call
+                before_unet()
             pred = unet3d_forward(sds["denoising_unet"], ucfg, lat_in, t, ehs[:nb], pose_cache[wi], banks, do_cfg)
             noise_pred[:, :, c] = noise_pred[:, :, c] + pred
             counter[:, :, c] = counter[:, :, c] + 1

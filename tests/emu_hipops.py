@@ -111,6 +111,8 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
     if rowbias is not None:
         idx = torch.arange(M) // rows_per_group
         y = y + rowbias.float()[idx][:, :N]
+    if act == 2:
+        y = y * torch.sigmoid(1.702 * y)
     if residual is not None:
         y = y + residual.float().reshape(M, -1)
     if trans_out:
@@ -119,7 +121,10 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
         y = y.reshape(M, N // head_dim, head_dim).permute(1, 0, 2)
     y = y.contiguous() if out_f32 else y.to(F16).contiguous()
     if out is not None:
-        out.copy_(y.reshape(out.shape))
+        if trans_out and ldo is not None and ldo != M:        # transposed rows at a padded pitch: out (N, ldo >= M)
+            out[:, :M].copy_(y)
+        else:
+            out.copy_(y.reshape(out.shape))
         return out
     return y
 
@@ -198,7 +203,7 @@ def ref_attention(q, ldq, k, ldk, vt, ldvt, n_frames, T, heads, d, kref=None, ld
     if kref is not None and kref_head_stride:
         kref = kref.reshape(heads, -1, d).permute(1, 0, 2).reshape(-1, C)
     K = k[:, :C].float().reshape(nsrc, T, heads, d).permute(0, 2, 1, 3)
-    V = vt.float().t().reshape(nsrc, T, heads, d).permute(0, 2, 1, 3)
+    V = vt[:, :nsrc * T].float().t().reshape(nsrc, T, heads, d).permute(0, 2, 1, 3)     # (rows may be padded to a 16-B pitch)
     out = torch.empty((n_frames, T, C), dtype=F32)
     for n in range(n_frames):
         Kn, Vn = K[n % nsrc], V[n % nsrc]
@@ -314,7 +319,7 @@ _EMULATED = ("groupnorm", "layernorm", "rowgemm320_supported", "groupnorm_scale_
 def install(monkeypatch):
     """Route aniportrait_amd.hipops through the emulation and let the HIP-backed modules pack their weights on
     the CPU (the product refuses to: `HipModel.packed()` raises off-GPU)."""
-    from aniportrait_amd import engine, hipops, modeling, pipeline_pose2vid_long, pose_guider
+    from aniportrait_amd import clip_vision, engine, hipops, modeling, pipeline_pose2vid_long, pose_guider
     g = globals()
     for name in _EMULATED:
         assert hasattr(hipops, name), name
@@ -328,3 +333,4 @@ def install(monkeypatch):
     monkeypatch.setattr(modeling.HipModel, "packed", packed)
     monkeypatch.setattr(pose_guider.PoseGuider, "packed", packed)
     monkeypatch.setattr(pipeline_pose2vid_long.Pose2VideoPipeline, "_require_gpu", staticmethod(lambda device: None))
+    monkeypatch.setattr(clip_vision.CLIPVisionHip, "_require_gpu", staticmethod(lambda device: None))

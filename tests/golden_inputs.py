@@ -62,6 +62,8 @@ REAL_PIPE_CASES = {
     # wrapping around the clip end), 1 DDIM step; stored frames sit in plain, overlapping and wrap-around windows
     "c4_1step": (512, 512, 150, 1, 3.5, 5, (0, 5, 12, 75, 146, 149)),
     "c5_25step": (768, 768, 16, 25, 3.5, 3, (0, 5, 10, 15)),      # BASELINE configs[4] geometry with its WHOLE 25-step schedule
+    # BASELINE configs[3] geometry over a MULTI-step schedule (round 6): the wrap-around window merge feeding the next step
+    "c4_4step": (512, 512, 150, 4, 3.5, 5, (0, 5, 12, 75, 146, 149)),
 }
 
 

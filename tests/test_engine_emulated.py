@@ -288,3 +288,32 @@ def test_cfg_shared_prefix_of_the_denoising_unet_changes_nothing(emu, gold, monk
     monkeypatch.setattr(engine, "_SHARE_CFG_PREFIX", False)
     assert torch.equal(unet.forward_nhwc(x, b, f, c["t"], c["ehs"], pose, cfg_shared_input=True).float(), outs[False])
     rd.clear(); wr.clear()
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("batch", [1, 2])
+def test_clip_vision_engine_matches_transformers(emu, batch):
+    """engine.clip_vision_forward (round 6: the CLIP image encoder on the HIP kernels; here on their emulation) against the
+    transformers module it adopts, fp32 on the CPU (pipeline_pose2vid_long.py:379-385): host-side im2col incl. the class
+    token's zero row and the K padding, class + position table as the patch GEMM's residual, pre-scaled q bias, quick-GELU,
+    post-LayerNorm of the class token, projection"""
+    from aniportrait_amd.clip_vision import CLIPVisionHip, patch_rows
+    enc = small_clip_encoder("cpu")
+    g = torch.Generator().manual_seed(11)
+    px = torch.randn((batch, 3, 224, 224), generator=g)
+    ref = enc(px).image_embeds
+    hip = CLIPVisionHip.from_module(enc)
+    rows = patch_rows(px, enc.config.patch_size)
+    assert rows.shape == (batch * 50, 3072) and float(rows[0].abs().max()) == 0.0
+    got = hip.image_embeds_from_rows(rows)
+    assert got.shape == ref.shape and got.dtype == torch.float16
+    assert rel_err(got.float(), ref) < 4e-3
+    assert rel_err(hip.image_embeds(px).float(), ref) < 4e-3
+    # 588 = 3 * 14 * 14 columns (ViT-L/14) are padded to a multiple of 64 with zeros
+    assert patch_rows(torch.randn(1, 3, 28, 28), 14).shape == (5, 640)
+    with pytest.raises(ValueError):
+        hip.image_embeds(torch.randn(1, 3, 192, 192))
+    bad = small_clip_encoder("cpu")
+    bad.config.hidden_act = "gelu"
+    with pytest.raises(NotImplementedError):
+        CLIPVisionHip.from_module(bad)

@@ -337,3 +337,60 @@ def test_inference_v1_pipeline_on_the_gpu(case):
     p = psnr(vid, gold[case + "/video_f16"].float())
     print(f"inference_v1 pipeline {case}: PSNR vs the reference's v1 run = {p:.2f} dB")
     assert p >= 40.0
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("width", ["small", "vit_l14"])
+def test_clip_vision_tower_matches_transformers(width):
+    """SURVEY §8 f2 (round 6): the CLIP image encoder of `pipeline_pose2vid_long.py:379-385` on the HIP kernels
+    (`engine.clip_vision_forward` through `clip_vision.CLIPVisionHip`) against the transformers module it adopts, run in fp32
+    on the CPU.  `vit_l14`: the real tower of the path — ViT-L/14, 24 layers, 257 tokens, d = 64, projection 768.
+    Tolerance 2e-3 of the embedding's largest component (fp16 storage between the ~220 launches, fp32 accumulation); the
+    pipeline's own `_clip_embeds` (hipGraph replay) must reproduce the eager result exactly, for two different images."""
+    from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
+
+    from aniportrait_amd import configs as C
+    from aniportrait_amd.clip_vision import CLIPVisionHip
+    from aniportrait_amd.synthetic import fill_module_, synth_ref_image
+    cfg = C.CLIP_SMALL if width == "small" else C.CLIP_VIT_L14
+    enc = fill_module_(CLIPVisionModelWithProjection(CLIPVisionConfig(**cfg)), 3, "image_encoder.").eval()
+    g = torch.Generator().manual_seed(5)
+    px = torch.randn((2, 3, 224, 224), generator=g).half().float()
+    ref = enc(px).image_embeds
+    hip = CLIPVisionHip.from_module(enc.to(DEV).half())
+    got = hip.image_embeds(px)
+    assert got.dtype == torch.float16 and got.shape == ref.shape
+    err = rel_err(got.float().cpu(), ref)
+    print(f"[clip {width}] rel err vs transformers fp32 = {err:.2e}")
+    assert err < 2e-3, err
+    one = hip.image_embeds(px[:1])
+    assert torch.equal(one, got[:1]), "batch 1 and batch 2 disagree on the first image"
+
+
+@torch.no_grad()
+def test_pipeline_clip_embeds_run_on_the_hip_tower():
+    """`Pose2VideoPipeline._clip_embeds`: PIL resize + CLIPImageProcessor on the host, im2col on the host, the tower as a
+    hipGraph of HIP kernels — equal to the eager call, different for a different image, close to the module's own fp32 result;
+    no torch kernel of the transformers module runs (its forward is never called: patched to raise)."""
+    from aniportrait_amd import configs as C
+    from aniportrait_amd.scheduling_ddim import DDIMScheduler
+    from aniportrait_amd.synthetic import synth_ref_image
+    from src.pipelines.pipeline_pose2vid_long import Pose2VideoPipeline
+    m, _ = build_hip_models(True)
+    enc = small_clip_encoder(DEV).half()
+    pipe = Pose2VideoPipeline(vae=m["vae"], image_encoder=enc, reference_unet=m["reference_unet"],
+                              denoising_unet=m["denoising_unet"], pose_guider=m["pose_guider"], scheduler=DDIMScheduler(**C.DDIM_V2))
+    img_a, img_b = synth_ref_image(128, 128, 1), synth_ref_image(128, 128, 2)
+    px = pipe.clip_image_processor.preprocess(img_a.resize((224, 224)), return_tensors="pt").pixel_values
+    want = enc.float()(px.to(DEV)).image_embeds.cpu()
+    enc.half()
+
+    def boom(*a, **k):
+        raise AssertionError("the transformers module's forward ran: the CLIP tower is not on the HIP kernels")
+    enc.forward = boom
+    a1 = pipe._clip_embeds(img_a, torch.device("cpu"))
+    b1 = pipe._clip_embeds(img_b, torch.device("cpu"))
+    a2 = pipe._clip_embeds(img_a, torch.device("cpu"))      # graph replay after another image went through the same buffers
+    assert a1.dtype == torch.float16 and tuple(a1.shape) == tuple(want.shape)
+    assert torch.equal(a1, a2) and not torch.equal(a1, b1)
+    assert rel_err(a1.float(), want) < 2e-3

@@ -88,6 +88,21 @@ def test_gemm_epilogues():
     close(out, 0.25 * base, "gemm alpha fp32-out", rtol=1e-4, arms=1e-4)
 
 
+@pytest.mark.parametrize("M,N,K", [(257, 4096, 1024), (50, 128, 64), (2056, 512, 256), (300, 200, 136)])
+def test_gemm_quick_gelu(M, N, K):
+    """act = 2 (round 6): x * sigmoid(1.702 x) on (acc + bias), ahead of the residual — fc1 of the CLIP vision tower's MLP
+    (transformers QuickGELUActivation); M = 257 = the tokens of one 224 x 224 image at patch 14.  Any M goes to the
+    small-problem kernel (the only epilogue that carries it)."""
+    ops = _ops()
+    A = rnd(M, K, seed=21).to(DEV)
+    W = rnd(N, K, seed=22, scale=2.0 * K ** -0.5).to(DEV)
+    bias = rnd(N, seed=23).float().to(DEV)
+    res = rnd(M, N, seed=24).to(DEV)
+    y = A.float() @ W.float().t() + bias
+    close(ops.gemm(A, W, bias, act=2), y * torch.sigmoid(1.702 * y), f"gemm quick-gelu {M}x{N}x{K}")
+    close(ops.gemm(A, W, bias, act=2, residual=res), y * torch.sigmoid(1.702 * y) + res.float(), f"gemm quick-gelu + residual {M}x{N}x{K}")
+
+
 def test_gemm_two_source():
     ops = _ops()
     M, K1, K2, N = 333, 128, 64, 136

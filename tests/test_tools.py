@@ -102,7 +102,7 @@ def test_pmc_summarize_effective_clock(tmp_path):
 
 
 def test_gpu_session_script_parses():
-    for script in ("tools/gpu_round4.sh", "tools/gpu_round5.sh"):
+    for script in ("tools/gpu_round4.sh", "tools/gpu_round5.sh", "tools/gpu_round6.sh"):
         subprocess.run(["bash", "-n", os.path.join(REPO, script)], check=True)
 
 
@@ -113,7 +113,7 @@ def test_bench_cpu_baseline_leg_at_toy_sizes():
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    r = bench.cpu_baseline(size=64, frames=2, c1=(64, 2, 1))
+    r = bench.cpu_baseline(size=64, frames=2, c1=(64, 2, 1), steps_timed=2)
     assert r["kind"] == "port" and r["extrapolated"] is True and r["unit"] == "frames/s" and r["cores"] >= 1
     assert r["ddim_steps_timed"] == 2 and r["step_seconds"] > 0 and r["vae_frame_seconds"] > 0 and r["fixed_seconds"] >= 0
     t_clip = r["fixed_seconds"] + 25 * r["step_seconds"] + 2 * r["vae_frame_seconds"]
