@@ -10,7 +10,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 # ANIP_LIB: an experiment build of the same ABI (aniportrait_amd/build.py --out=...); the product is the default path
 LIB_PATH = os.environ.get("ANIP_LIB") or os.path.join(HERE, "lib", "libaniportrait_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 c_void_p, c_int, c_int64, c_float = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -35,6 +35,7 @@ class GemmParams(C.Structure):
         ("trans_out", c_int),
         ("workspace", c_void_p), ("workspace_bytes", c_int64),
         ("head_dim", c_int),
+        ("splitk_tickets", c_void_p),
     ]
 
 
@@ -52,6 +53,7 @@ SIGNATURES = {
     "anip_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_int64,
                                c_int, c_void_p]),
     "anip_gemm_workspace_bytes": (c_int64, [C.POINTER(GemmParams)]),
+    "anip_gemm_splitk_ticket_ints": (c_int64, [C.POINTER(GemmParams)]),
     "anip_gemm": (c_int, [C.POINTER(GemmParams), c_void_p]),
     "anip_ffn_geglu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                c_void_p]),

@@ -474,12 +474,15 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
     // start the accumulators from the per-column additive terms (bias and, when the block's rows share one row group,
     // the row-group bias): NB small L2-resident loads that travel with the prologue DMA, no registers, and nothing
     // left to fetch for them in the epilogue, where loads queue behind the tile's stores (see there).
-    const bool acc_has_bias = !TRANS && splitk <= 1 && p.alpha == 1.0f && m0 + BM2 <= p.M && n0 + BN <= p.N &&
-                              (p.bias != nullptr || p.rowbias != nullptr) &&
-                              (p.rowbias == nullptr || (((p.ld_rowbias & 3) == 0) && ((((uintptr_t)p.rowbias) & 15) == 0)));
+    // (split-K with the in-kernel reduction: the slices start from zero and the LAST ARRIVER adds the terms to the reduced tile)
+    const bool sk_inkernel = splitk > 1 && p.splitk_tickets != nullptr;
+    const bool bias_ok = !TRANS && (splitk <= 1 || sk_inkernel) && p.alpha == 1.0f && m0 + BM2 <= p.M && n0 + BN <= p.N &&
+                         (p.bias != nullptr || p.rowbias != nullptr) &&
+                         (p.rowbias == nullptr || (((p.ld_rowbias & 3) == 0) && ((((uintptr_t)p.rowbias) & 15) == 0)));
+    const bool acc_has_bias = bias_ok;      // true at the epilogue in both forms
     const bool rb_uni = acc_has_bias && p.rowbias != nullptr &&
                         (m0 / p.rows_per_group == (m0 + BM2 - 1) / p.rows_per_group);
-    if (!TRANS && acc_has_bias) {
+    auto add_col_terms = [&](bool init) {
       const float* rb_row = rb_uni ? p.rowbias + (int64_t)(m0 / p.rows_per_group) * p.ld_rowbias : nullptr;
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
@@ -488,9 +491,10 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
         if (p.bias != nullptr) b = *(const f32x4*)(p.bias + cb);
         if (rb_uni) b += *(const f32x4*)(rb_row + cb);
 #pragma unroll
-        for (int i = 0; i < FM; ++i) acc[i][j] = b;
+        for (int i = 0; i < FM; ++i) acc[i][j] = init ? b : acc[i][j] + b;
       }
-    }
+    };
+    if (!TRANS && acc_has_bias && !sk_inkernel) add_col_terms(true);
 
     if constexpr (PHASED) {
       // K-tile 0 (issued in front of the tile loop / in front of the previous tile's epilogue) has landed for every wave;
@@ -616,6 +620,72 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
 #pragma unroll
         for (int j = 0; j < NB; ++j) asm volatile("" ::"v"(acc[i][j]));
       return;               // (ends a persistent walk, too)
+    }
+    if (sk_inkernel) {
+      // ---- split-K, reduced INSIDE the launch (round 6; cdna_hip_programming.md §5 "in-launch split-K reduction", the
+      // Guideline-16 hand-off in its counter form).  Slice blockIdx.y of tile vb draws an arrival ticket; every slice but the
+      // last arriver publishes its fp32 accumulators — in REGISTER layout, fragment-major: one 1-KB run per wave and store —
+      // behind an agent-scope release and counts itself done; the last arriver, which keeps its own partial in registers,
+      // waits for the S - 1 publishers (they are running: a ticket holder is resident, so the wait is bounded and needs no
+      // co-scheduling assumption), acquires, and adds the slabs in SLICE order — the same sum whatever the arrival order
+      // (S == 2: a + b == b + a; S > 2: its own accumulators go through its slab, too, so that every term comes from memory
+      // in order) — then runs the ordinary epilogue.  Both counters return to zero for the next launch that is handed these
+      // words.  Placement-independent; a tile's slices share an XCD (and the slabs stay in its L2) when nblk % 8 == 0.
+      constexpr int FRAGS = FM * NB;
+      float* wsf = (float*)p.workspace;
+      const int64_t slab = (int64_t)FRAGS * NT2 * 4;                  // floats per (slice, tile)
+      int* tk = (int*)p.splitk_tickets + 2 * vb;                       // { arrived, published }
+      const int slice = (int)blockIdx.y;
+      auto slab_of = [&](int s_) -> float* { return wsf + ((int64_t)s_ * nblk + vb) * slab + (int64_t)tid * 4; };
+      auto dump = [&](float* dst) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < NB; ++j) *(f32x4*)(dst + (int64_t)(i * NB + j) * NT2 * 4) = acc[i][j];
+      };
+      __syncthreads();                                                 // every wave is through its last LDS read: smem is free
+      if (tid == 0) *(volatile int*)smem = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const int ticket = *(volatile int*)smem;
+      if (ticket != splitk - 1) {
+        dump(slab_of(slice));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __hip_atomic_fetch_add(tk + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+      }
+      if (tid == 0) {
+        while (__hip_atomic_load(tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != splitk - 1) __builtin_amdgcn_s_sleep(4);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(tk + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      if (splitk == 2) {
+        const float* src = slab_of(slice ^ 1);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < NB; ++j) acc[i][j] += *(const f32x4*)(src + (int64_t)(i * NB + j) * NT2 * 4);
+      } else {
+        dump(slab_of(slice));           // own lanes read back what they wrote: program order, no fence
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s_ = 0; s_ < splitk; ++s_) {
+          const float* src = slab_of(s_);
+#pragma unroll
+          for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) acc[i][j] += *(const f32x4*)(src + (int64_t)(i * NB + j) * NT2 * 4);
+        }
+      }
+      if (!TRANS && acc_has_bias) add_col_terms(false);
     }
     float alpha = p.alpha;
     // what the accumulators already carry of the per-column additive terms (see acc_has_bias above)
@@ -1097,7 +1167,8 @@ int launch_gemm2(const anip_gemm_params& p, hipStream_t stream, int splitk = 1) 
     const unsigned ncu = (unsigned)gemm2_cu_count();
     if (ncu >= 8 && (ncu & 7) == 0 && grid > ncu) grid = ncu;
   }
-  hipLaunchKernelGGL((gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS>), dim3(grid, (unsigned)p.batch, 1),
+  const unsigned gy = (splitk > 1 && p.splitk_tickets != nullptr) ? (unsigned)splitk : (unsigned)p.batch;
+  hipLaunchKernelGGL((gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS>), dim3(grid, gy, 1),
                      dim3(NT2), LDS, stream, p, 0, splitk);
   return 1;
 }
@@ -1162,10 +1233,45 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // split factor for problems with too few tiles to fill the chip (1 = no split); *cfg = tile configuration:
 // 128 / 160: 128-row 4-wave tiles of that width; 256 / 320: the wide 256-row tiles of that width
+// ANIP_SK_FORCE="<bn>:<S>" (experiments, read once): every eligible problem is split into S slices of the tile configuration bn
+// (128 / 160: 128-row 4-wave tiles; 256 / 320: the wide 256-row tiles) — how the split rules below were measured
+static bool sk_forced(int* bn, int* S) {
+  static int fbn = -1, fS = 0;
+  if (fbn < 0) {
+    fbn = 0;
+    const char* e = getenv("ANIP_SK_FORCE");
+    if (e != nullptr) {
+      int a = 0, b = 0;
+      if (sscanf(e, "%d:%d", &a, &b) == 2 && (a == 128 || a == 160 || a == 256 || a == 320) && b >= 1 && b <= 32) { fbn = a; fS = b; }
+    }
+  }
+  *bn = fbn; *S = fS;
+  return fbn > 0;
+}
+static int sk_rules() {      // ANIP_SK_RULES=0: the round-3..5 rules only (A/B measurements)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("ANIP_SK_RULES"); v = (e != nullptr && e[0] == '0') ? 0 : 1; }
+  return v;
+}
+
 static int gemm2_split(const anip_gemm_params& p, int* cfg) {
   if (p.batch > 1 || p.act == 1 || p.trans_out || p.M < 64 || p.M > 16384 || (p.N & 3) != 0) return 1;
   if (p.conv ? (p.Cin % 32 != 0) : (p.A2 != nullptr && (p.K1 % 32) != 0)) return 1;
   if ((((uintptr_t)p.bias | (uintptr_t)p.rowbias) & 15) != 0) return 1;
+  {
+    int fbn, fS;
+    if (sk_forced(&fbn, &fS)) {
+      const bool wide = fbn >= 256;
+      const bool k64 = p.conv ? (p.Cin % 64 == 0) : (p.A2 == nullptr || p.K1 % 64 == 0);
+      if (wide && !k64) return 1;
+      const int nk = (p.K + (wide ? 63 : 31)) / (wide ? 64 : 32);
+      int S = min(fS, nk / 2);
+      if (S < 2) return 1;
+      *cfg = fbn;
+      const int per = (nk + S - 1) / S;
+      return (nk + per - 1) / per;
+    }
+  }
   if (p.M < 1024) {
     // A handful of 128-row tiles under a long K: the once-per-clip ReferenceNet at its 8x8 / 16x16 levels (M = 128 / 512 for
     // the CFG pair of one reference frame; its 3x3 convolutions stream 29-59 MB of weights through 10 workgroups of the
@@ -1222,10 +1328,26 @@ static int gemm2_split(const anip_gemm_params& p, int* cfg) {
   return (nk + per - 1) / per;               // every slice non-empty
 }
 
+// tiles of the split configuration (the in-kernel reduction keeps one fp32 slab per (slice, tile), tile-padded, in register layout)
+static int64_t sk_tiles(const anip_gemm_params& p, int bn, int* bm_out) {
+  const int bm = bn >= 256 ? 256 : 128;
+  if (bm_out) *bm_out = bm;
+  return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
+}
+
 int64_t anip_gemm2_workspace_bytes(const anip_gemm_params& p) {
-  int bn;
+  int bn = 128, bm;
   const int S = gemm2_split(p, &bn);
-  return S > 1 ? (int64_t)S * p.M * p.N * 4 : 0;
+  if (S <= 1) return 0;
+  const int64_t tiles = sk_tiles(p, bn, &bm);
+  return (int64_t)S * tiles * bm * bn * 4;       // >= S * M * N * 4, the [split][M][N] form of the two-pass path
+}
+
+// ints of zeroed device memory the in-kernel reduction wants in `splitk_tickets` (two per output tile), 0 if the problem is not split
+int64_t anip_gemm2_ticket_ints(const anip_gemm_params& p) {
+  int bn = 128;
+  const int S = gemm2_split(p, &bn);
+  return S > 1 ? 2 * sk_tiles(p, bn, nullptr) : 0;
 }
 
 // split-K path: 1 if launched (partials + reduce), 0 if the problem is not split, < 0 on error
@@ -1234,13 +1356,23 @@ int anip_gemm2_try_splitk(const anip_gemm_params& p, hipStream_t stream) {
   int bn = 128;
   const int S = gemm2_split(p, &bn);
   if (S <= 1) return 0;
-  const int64_t need = (int64_t)S * p.M * p.N * 4;
+  const int64_t need = anip_gemm2_workspace_bytes(p);
   if (p.workspace == nullptr || p.workspace_bytes < need || (((uintptr_t)p.workspace) & 15) != 0) {
     anip_set_error("anip_gemm: this problem is split over K and needs %lld bytes of 16-B aligned workspace "
                    "(anip_gemm_workspace_bytes); got %lld", (long long)need, (long long)p.workspace_bytes);
     return -1;
   }
+  if (p.splitk_tickets != nullptr) {
+    // reduced inside the launch by each tile's last-arriving slice, which then runs the ordinary epilogue (see the kernel)
+    if ((((uintptr_t)p.out | (uintptr_t)p.bias | (uintptr_t)p.residual) & 15) == 0 && (((uintptr_t)p.splitk_tickets) & 3) == 0) {
+      if (bn == 128) return dispatch_gemm2<128, 128, 4, 2, 32, 3>(p, stream, S);
+      if (bn == 160) return dispatch_gemm2<128, 160, 4, 2, 32, 3>(p, stream, S);
+      if (bn == 256) return dispatch_gemm2<256, 256, 8, 4, 64, 2>(p, stream, S);
+      return dispatch_gemm2<256, 320, 8, 4, 64, 2>(p, stream, S);
+    }
+  }
   anip_gemm_params q = p;
+  q.splitk_tickets = nullptr;
   q.out = p.workspace; q.ldo = p.N; q.out_f32 = 1;
   q.alpha = 1.0f; q.bias = nullptr; q.rowbias = nullptr; q.residual = nullptr;
   q.head_dim = 0;            // partial tiles are plain [split][M][N]; the reduce kernel applies the output mapping

@@ -161,8 +161,8 @@ def extra_configs(pipe, seed=0):
     return out
 
 
-CPU_BASELINE_THREADS = 64     # fixed (min with the schedulable cores): the oracle's conv / linear kernels stop scaling
-#                               there on the GPU box's host (round-2 scan: 64 -> 1.3 ms, 256 -> 500 ms per 320-ch 3x3 conv)
+CPU_BASELINE_THREADS = 64     # upper bound (min with the schedulable cores AND the container's CPU quota): the oracle's conv / linear
+#                               kernels stop scaling there on an unthrottled host (round-2 scan: 64 -> 1.3 ms, 256 -> 500 ms per 3x3 conv)
 CPU_BASELINE_STEPS = 3        # DDIM steps of the fixed sample (BASELINE configs[0] has 10)
 
 
@@ -190,7 +190,9 @@ def cpu_baseline(size=512, frames=16, c1=(256, 4, None), steps_timed=1, threads=
     except AttributeError:
         ncpu = os.cpu_count()
     quota = hostcfg.cpu_quota()
-    threads = max(1, min(CPU_BASELINE_THREADS, ncpu)) if threads is None else int(threads)
+    # min(64, schedulable cores, the cgroup's CPU quota): under the MI355X box's 16-CPU quota 64 threads are throttled — the oracle's
+    # UNet3D call at 256x256 took 4.4 s on 16 threads, 4.8 s on 32, 7.8 s on 64 (round 6, profiles/r06/f_cpu_threads_probe.jsonl)
+    threads = max(1, min(CPU_BASELINE_THREADS, hostcfg.usable_cpus())) if threads is None else int(threads)
     torch.set_num_threads(threads)
     g = torch.Generator().manual_seed(0)
 

@@ -363,8 +363,8 @@ def test_clip_vision_tower_matches_transformers(width):
     err = rel_err(got.float().cpu(), ref)
     print(f"[clip {width}] rel err vs transformers fp32 = {err:.2e}")
     assert err < 2e-3, err
-    one = hip.image_embeds(px[:1])
-    assert torch.equal(one, got[:1]), "batch 1 and batch 2 disagree on the first image"
+    one = hip.image_embeds(px[:1])          # (another M: other tiles / K splits in the GEMMs, so close, not bit-equal)
+    assert rel_err(one.float().cpu(), ref[:1]) < 2e-3
 
 
 @torch.no_grad()

@@ -192,6 +192,22 @@ def main():
         bench_gemm(128, 1280, 1280, "refnet 8^2 out-proj", res=True)
         bench_gemm(128, 1280, 2560, "refnet 8^2 shortcut (concat)", a2=1280)
         bench_gemm(8192, 8192, 8192, "square 8k")
+    if "sk" in (only or ()):   # the tile-starved levels (round 6: split-K reduced inside the launch): ANIP_SK_FORCE=<bn>:<S> sweeps
+        bench_gemm(NF * 256, 1280, 1280, "16^2 out-proj x4", res=True)
+        bench_gemm(NF * 256, 1280, 1280, "16^2 proj_in / to_q")
+        bench_gemm(NF * 256, 3840, 1280, "16^2 temporal qkv x2")
+        bench_gemm(NF * 256, 1280, 5120, "16^2 ff-out x2", res=True)
+        bench_gemm(NF * 256, 1280, 2560, "16^2 shortcut (concat)", a2=1280)
+        bench_gemm(NF * 64, 1280, 1280, "8^2 out-proj", res=True)
+        bench_gemm(NF * 64, 3840, 1280, "8^2 temporal qkv")
+        bench_gemm(NF * 64, 1280, 5120, "8^2 ff-out", res=True)
+        bench_gemm(NF * 64, 1280, 2560, "8^2 shortcut 2560->1280 (concat)", a2=1280)
+        bench_gemm(NF * 1024, 640, 640, "32^2 out-proj x4", res=True)
+        bench_gemm(NF * 1024, 640, 2560, "32^2 ff-out x2", res=True)
+        bench_conv(NF, 16, 1280, 1280, "res 16^2 1280 conv2", res=True)
+        bench_conv(NF, 16, 2560, 1280, "res 16^2 2560->1280 conv1", rb=True)
+        bench_conv(NF, 8, 1280, 1280, "res 8^2 1280 conv2", res=True)
+        bench_conv(NF, 8, 2560, 1280, "res 8^2 2560->1280 conv1", rb=True)
     if want("conv"):
         bench_conv(NF, 64, 320, 320, "res 64^2 320 conv2", res=True)
         bench_conv(NF, 64, 320, 320, "res 64^2 320 conv1", rb=True)
