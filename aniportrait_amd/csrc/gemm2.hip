@@ -69,7 +69,10 @@ __device__ __forceinline__ void row_swap(float& x, float& y) {
 //     flop drops by 1/4..1/3 and every DMA row is a full 128-B line (BK = 32 rows are half lines), which is what
 //     bounds the smaller tiles (measured: DMA alone = 0.93 ms of the 1.18 ms 8192^3 GEMM).
 //   wide tiles (NST = 2, BK = 64, 8 waves): the quarter-phased main loop (round 3), see "quarter-phased schedule" below.
-template <int BM2, int BN, int NW, int WNW, int BKT, int NST, bool CONV, bool TRANS>
+// SK: the instantiations that carry the in-launch split-K reduction (launched only for split problems with arrival counters).
+// A template parameter, not a runtime branch: with the reduction's code inside them the wide tiles' register allocation changes
+// and their MAIN LOOP spills (scratch 0 -> 540-820 B per lane; every wide-tile launch of the path 2-3x slower, round 6).
+template <int BM2, int BN, int NW, int WNW, int BKT, int NST, bool CONV, bool TRANS, bool SK = false>
 __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void gemm2_kernel(const anip_gemm_params p,
                                                                                            const int skip_epilogue, const int splitk) {
   constexpr int NT2 = NW * 64;
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
     // the row-group bias): NB small L2-resident loads that travel with the prologue DMA, no registers, and nothing
     // left to fetch for them in the epilogue, where loads queue behind the tile's stores (see there).
     // (split-K with the in-kernel reduction: the slices start from zero and the LAST ARRIVER adds the terms to the reduced tile)
-    const bool sk_inkernel = splitk > 1 && p.splitk_tickets != nullptr;
+    const bool sk_inkernel = SK && splitk > 1 && p.splitk_tickets != nullptr;
     const bool bias_ok = !TRANS && (splitk <= 1 || sk_inkernel) && p.alpha == 1.0f && m0 + BM2 <= p.M && n0 + BN <= p.N &&
                          (p.bias != nullptr || p.rowbias != nullptr) &&
                          (p.rowbias == nullptr || (((p.ld_rowbias & 3) == 0) && ((((uintptr_t)p.rowbias) & 15) == 0)));
@@ -621,7 +624,7 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
         for (int j = 0; j < NB; ++j) asm volatile("" ::"v"(acc[i][j]));
       return;               // (ends a persistent walk, too)
     }
-    if (sk_inkernel) {
+    if constexpr (SK) if (sk_inkernel) {
       // ---- split-K, reduced INSIDE the launch (round 6; cdna_hip_programming.md §5 "in-launch split-K reduction", the
       // Guideline-16 hand-off in its counter form).  Slice blockIdx.y of tile vb draws an arrival ticket; every slice but the
       // last arriver publishes its fp32 accumulators — in REGISTER layout, fragment-major: one 1-KB run per wave and store —
@@ -636,19 +639,30 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
       const int64_t slab = (int64_t)FRAGS * NT2 * 4;                  // floats per (slice, tile)
       int* tk = (int*)p.splitk_tickets + 2 * vb;                       // { arrived, published }
       const int slice = (int)blockIdx.y;
-      auto slab_of = [&](int s_) -> float* { return wsf + ((int64_t)s_ * nblk + vb) * slab + (int64_t)tid * 4; };
-      auto dump = [&](float* dst) {
+      // slabs through buffer descriptors: one VGPR (tid * 16) + a scalar fragment offset per access.  With flat pointers every
+      // one of the FM * NB fragment addresses is a 64-bit VGPR pair (their 8-KB steps do not fit an instruction offset) that
+      // the compiler computes up front: + 80 VGPRs next to 160 accumulator registers, and the wide tiles' main loop spills.
+      auto slab_rsrc = [&](int s_) {
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(wsf + ((int64_t)s_ * nblk + vb) * slab), 0, (uint32_t)(slab * 4), 0x00020000);
+      };
+      const int tvo = tid * 16;
+      auto dump = [&](int s_) {
+        const auto rs = slab_rsrc(s_);
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
-          for (int j = 0; j < NB; ++j) *(f32x4*)(dst + (int64_t)(i * NB + j) * NT2 * 4) = acc[i][j];
+          for (int j = 0; j < NB; ++j) {
+            union { f32x4 f; u32x4 u; } c;
+            c.f = acc[i][j];
+            __builtin_amdgcn_raw_buffer_store_b128(c.u, rs, tvo, (i * NB + j) * NT2 * 16, 0);
+          }
       };
       __syncthreads();                                                 // every wave is through its last LDS read: smem is free
       if (tid == 0) *(volatile int*)smem = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __syncthreads();
       const int ticket = *(volatile int*)smem;
       if (ticket != splitk - 1) {
-        dump(slab_of(slice));
+        dump(slice);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
@@ -665,25 +679,36 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
         __hip_atomic_store(tk + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __syncthreads();
+      // (one row of fragments — NB loads — in flight at a time)
+      auto add_slab = [&](int s_) {
+        const auto rs = slab_rsrc(s_);
+        int vo = tvo;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          f32x4 t[NB];
+#pragma unroll
+          for (int j = 0; j < NB; ++j) {
+            union { f32x4 f; u32x4 u; } c;
+            c.u = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (i * NB + j) * NT2 * 16, 0);
+            t[j] = c.f;
+          }
+#pragma unroll
+          for (int j = 0; j < NB; ++j) acc[i][j] += t[j];
+          // the next row's address "depends" on this row's last sum: the buffer-load intrinsics float above a plain
+          // memory-clobber asm, and with all FM * NB loads in flight the wide tiles have 160 + 160 live registers
+          asm volatile("" : "+v"(vo) : "v"(acc[i][NB - 1]));
+        }
+      };
       if (splitk == 2) {
-        const float* src = slab_of(slice ^ 1);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int j = 0; j < NB; ++j) acc[i][j] += *(const f32x4*)(src + (int64_t)(i * NB + j) * NT2 * 4);
+        add_slab(slice ^ 1);
       } else {
-        dump(slab_of(slice));           // own lanes read back what they wrote: program order, no fence
+        dump(slice);                    // own lanes read back what they wrote: program order, no fence
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
           for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int s_ = 0; s_ < splitk; ++s_) {
-          const float* src = slab_of(s_);
-#pragma unroll
-          for (int i = 0; i < FM; ++i)
-#pragma unroll
-            for (int j = 0; j < NB; ++j) acc[i][j] += *(const f32x4*)(src + (int64_t)(i * NB + j) * NT2 * 4);
-        }
+        for (int s_ = 0; s_ < splitk; ++s_) add_slab(s_);
       }
       if (!TRANS && acc_has_bias) add_col_terms(false);
     }
@@ -1167,8 +1192,22 @@ int launch_gemm2(const anip_gemm_params& p, hipStream_t stream, int splitk = 1) 
     const unsigned ncu = (unsigned)gemm2_cu_count();
     if (ncu >= 8 && (ncu & 7) == 0 && grid > ncu) grid = ncu;
   }
-  const unsigned gy = (splitk > 1 && p.splitk_tickets != nullptr) ? (unsigned)splitk : (unsigned)p.batch;
-  hipLaunchKernelGGL((gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS>), dim3(grid, gy, 1),
+  if constexpr (!TRANS && ((NW == 4 && BKT == 32) || (NW == 8 && BKT == 64 && NST == 2))) {   // the four split configurations
+    if (splitk > 1 && p.splitk_tickets != nullptr) {
+      auto ksk = gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS, true>;
+      if (anip_raise_lds_limit((const void*)ksk, LDS) != 0) {
+        anip_set_error("anip_gemm: cannot raise the dynamic LDS limit to %d bytes", LDS);
+        return -2;
+      }
+      hipLaunchKernelGGL(ksk, dim3(grid, (unsigned)splitk, 1), dim3(NT2), LDS, stream, p, 0, splitk);
+      return 1;
+    }
+  }
+  if (splitk > 1 && p.splitk_tickets != nullptr) {
+    anip_set_error("anip_gemm: internal: in-launch split-K on a tile configuration without the reduction");
+    return -2;
+  }
+  hipLaunchKernelGGL((gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS>), dim3(grid, (unsigned)p.batch, 1),
                      dim3(NT2), LDS, stream, p, 0, splitk);
   return 1;
 }

@@ -362,16 +362,16 @@ def test_ref_attention_peaky_with_reference(d, T):
     close(out, torch.cat(refs, 0), f"ref_attention peaky d={d} T={T}", rtol=6e-3, arms=6e-3)
 
 
-def _attn_log2_case(ops, d, T, heads, Nf, ridx, seed, scale=1.0, head_major=True):
+def _attn_log2_case(ops, d, T, heads, Nf, ridx, seed, scale=1.0, head_major=True, vscale=1.0):
     """q pre-multiplied by scale * log2(e) (ANIP_ATTN_Q_LOG2_SCALED), K head-major, V^T: the engine's operand layouts.
     Returns (out, fp64 reference computed from the SAME rounded q)."""
     Cc = heads * d
     Nref = 2
     qs = (rnd(Nf * T, Cc, seed=seed, scale=scale).float() * ops.attn_q_alpha(d)).half().to(DEV)
     k = rnd(Nf * T, Cc, seed=seed + 1, scale=scale).to(DEV)
-    v = rnd(Nf * T, Cc, seed=seed + 2).to(DEV)
+    v = rnd(Nf * T, Cc, seed=seed + 2, scale=vscale).to(DEV)
     kref = rnd(Nref * T, Cc, seed=seed + 3, scale=scale).to(DEV)
-    vref = rnd(Nref * T, Cc, seed=seed + 4).to(DEV)
+    vref = rnd(Nref * T, Cc, seed=seed + 4, scale=vscale).to(DEV)
     ref_index = torch.tensor(ridx, dtype=torch.int32, device=DEV)
     k_hm = k.reshape(Nf * T, heads, d).permute(1, 0, 2).contiguous()
     kr_hm = kref.reshape(Nref * T, heads, d).permute(1, 0, 2).contiguous()
@@ -422,6 +422,49 @@ def test_ref_attention_log2_scaled_peaky(d, T):
     close(out, ref, f"ref_attention log2-scaled peaky d={d} T={T}", rtol=6e-3, arms=6e-3)
     out, ref = _attn_log2_case(ops, d, T, heads=8, Nf=2, ridx=[1, -1], seed=365 + d, scale=2.0, head_major=False)
     close(out, ref, f"ref_attention log2-scaled peaky token-major d={d} T={T}", rtol=6e-3, arms=6e-3)
+
+
+@pytest.mark.parametrize("d,T", [(40, 1024), (80, 512), (160, 256), (64, 200)])
+def test_ref_attention_fp16_range_stress(d, T):
+    """Round 6 (the weights of every other test are name-hash synthetic, unit scale): what outlier channels of a real SD-1.5
+    checkpoint do to the attention operands.  q, k ~ N(0, 24^2): base-2 logits of standard deviation ~830, largest ~2^12 —
+    the running maximum (d = 40: an fp16 hi / lo pair riding in the contraction) sits far outside the lazy-rescale band and
+    every row is nearly one-hot; v ~ N(0, 2^12^2): outputs up to ~2^14, a quarter of the fp16 range.  Finite, and within the
+    peaky-row tolerance of the fp64 reference on the same rounded operands — both kernels (d = 64, T = 200: the first one)."""
+    ops = _ops()
+    out, ref = _attn_log2_case(ops, d, T, heads=8 if d != 64 else 2, Nf=2, ridx=[-1, 0], seed=700 + d, scale=24.0, vscale=4096.0)
+    assert float(ref.abs().max()) > 8192.0
+    close(out, ref, f"ref_attention range stress d={d} T={T}", rtol=6e-3, arms=6e-3)
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_ffn_geglu_fp16_range_stress(fused):
+    """Round 6: outlier channels through the GEGLU feed-forward.  Four input channels carry 200x the others' magnitude
+    (values up to ~850), so the value / gate pre-activations reach ~2^8 and the hidden activations
+    h * gelu(g) — held in fp16 between the two contractions, in LDS (fused) or HBM (two GEMMs) — reach 2^13..2^15 (asserted,
+    and below the fp16 maximum).  The erf polynomial must saturate cleanly at |g| >> 1; finite outputs within the FFN tolerance."""
+    ops = _ops()
+    M, Cc = 4096, 320
+    x = rnd(M, Cc, seed=730)
+    x[:, [7, 100, 211, 300]] *= 200.0
+    W1 = rnd(8 * Cc, Cc, seed=731, scale=1.2 * Cc ** -0.5)
+    b1 = rnd(8 * Cc, seed=732).float()
+    W2 = rnd(Cc, 4 * Cc, seed=733, scale=(4 * Cc) ** -0.5)
+    b2 = rnd(Cc, seed=734).float()
+    res = rnd(M, Cc, seed=735)
+    hv, hg = (_ref_mm(x, W1) + b1).chunk(2, dim=-1)
+    h32 = hv * F.gelu(hg)
+    assert 8192.0 < float(h32.abs().max()) < 60000.0, float(h32.abs().max())
+    ref = _ref_mm(h32.half(), W2) + b2 + res.float()
+    w1p, b1p = ops.pack_geglu(W1, b1)
+    xd = x.to(DEV)
+    if fused:
+        out = ops.ffn_geglu(xd, w1p.to(DEV), b1p.to(DEV), W2.to(DEV), b2.to(DEV), res.to(DEV))
+    else:
+        h = ops.gemm(xd, w1p.to(DEV), b1p.to(DEV), act=1)
+        close(h, h32, "GEGLU epilogue range stress", rtol=3e-3, arms=1e-3)
+        out = ops.gemm(h, W2.to(DEV), b2.to(DEV), residual=res.to(DEV))
+    close(out, ref, f"ffn_geglu range stress fused={fused}", rtol=3e-3, arms=3e-3)
 
 
 @pytest.mark.parametrize("d", [40, 80, 160])
@@ -564,8 +607,19 @@ def test_temporal_qkv_attention_fused(B, T, wscale, with_pe):
     bpe = (beta[None, :] + pe).contiguous().to(DEV)
     wp = ops.pack_temporal_qkv(wq.to(DEV), wk.to(DEV), wv.to(DEV))
     out = ops.temporal_qkv_attention(xd, gd, bpe, wp, B, Fr, T, heads)
+    # Why not the file header's 2e-3 for every element: that bound is ONE fp16 rounding of an fp32-accumulated result.  This
+    # kernel — like the three launches it replaces — rounds three times in sequence (normalised rows, q | k | v, probabilities),
+    # and the reference above rounds at the same points but accumulates in another order: wherever an fp32 sum lands within
+    # an ulp of a rounding boundary, q / k / v differ by one fp16 ulp and the softmax carries that flip into a whole row.  So the
+    # bound is stated as a distribution (round 6): the BULK within the single-rounding 2e-3, every element within 4e-3
+    # (8e-3 for the peaky rows of wscale = 2).
     tol = 4e-3 if wscale <= 1.0 else 8e-3      # peaky rows: a flipped fp16 rounding of one q / k element moves a probability by ~1 %
     close(out, ref, f"temporal_qkv_attention B{B} T{T} wscale{wscale}", rtol=tol, arms=tol)
+    o32, r32 = out.float().cpu(), ref.float()
+    rms = r32.pow(2).mean().sqrt().item()
+    outside = ((o32 - r32).abs() > 2e-3 * r32.abs() + 2e-3 * rms + 1e-6).float().mean().item()
+    print(f"[temporal_qkv_attention B{B} T{T} wscale{wscale}] fraction outside the single-rounding 2e-3 band: {outside:.2e}")
+    assert outside <= (2e-3 if wscale <= 1.0 else 2e-2), outside
     nh = ops.layernorm(xd, gd, beta.to(DEV), pe=pe.contiguous().to(DEV), rows_per_frame=T, frames=Fr)
     qkv = ops.gemm(nh, torch.cat([wq, wk, wv]).to(DEV))
     three = ops.temporal_attention(qkv, B, Fr, T, heads, d)
