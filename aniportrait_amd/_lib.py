@@ -35,7 +35,6 @@ class GemmParams(C.Structure):
         ("trans_out", c_int),
         ("workspace", c_void_p), ("workspace_bytes", c_int64),
         ("head_dim", c_int),
-        ("splitk_tickets", c_void_p),
     ]
 
 
@@ -53,7 +52,6 @@ SIGNATURES = {
     "anip_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p, c_int64,
                                c_int, c_void_p]),
     "anip_gemm_workspace_bytes": (c_int64, [C.POINTER(GemmParams)]),
-    "anip_gemm_splitk_ticket_ints": (c_int64, [C.POINTER(GemmParams)]),
     "anip_gemm": (c_int, [C.POINTER(GemmParams), c_void_p]),
     "anip_ffn_geglu": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                c_void_p]),

@@ -26,7 +26,6 @@
 int anip_gemm2_try(const anip_gemm_params& p, hipStream_t stream);  // gemm2.hip
 int anip_gemm2_try_splitk(const anip_gemm_params& p, hipStream_t stream);
 int64_t anip_gemm2_workspace_bytes(const anip_gemm_params& p);
-int64_t anip_gemm2_ticket_ints(const anip_gemm_params& p);
 
 namespace {
 
@@ -323,13 +322,6 @@ extern "C" int64_t anip_gemm_workspace_bytes(const anip_gemm_params* pp) {
     return 0;
   if (p.act == 2) return 0;
   return anip_gemm2_workspace_bytes(p);
-}
-
-extern "C" int64_t anip_gemm_splitk_ticket_ints(const anip_gemm_params* pp) {
-  if (anip_gemm_workspace_bytes(pp) <= 0) return 0;
-  anip_gemm_params p = *pp;
-  if (p.batch < 1) p.batch = 1;
-  return anip_gemm2_ticket_ints(p);
 }
 
 extern "C" int anip_gemm(const anip_gemm_params* pp, void* stream) {

@@ -69,10 +69,7 @@ __device__ __forceinline__ void row_swap(float& x, float& y) {
 //     flop drops by 1/4..1/3 and every DMA row is a full 128-B line (BK = 32 rows are half lines), which is what
 //     bounds the smaller tiles (measured: DMA alone = 0.93 ms of the 1.18 ms 8192^3 GEMM).
 //   wide tiles (NST = 2, BK = 64, 8 waves): the quarter-phased main loop (round 3), see "quarter-phased schedule" below.
-// SK: the instantiations that carry the in-launch split-K reduction (launched only for split problems with arrival counters).
-// A template parameter, not a runtime branch: with the reduction's code inside them the wide tiles' register allocation changes
-// and their MAIN LOOP spills (scratch 0 -> 540-820 B per lane; every wide-tile launch of the path 2-3x slower, round 6).
-template <int BM2, int BN, int NW, int WNW, int BKT, int NST, bool CONV, bool TRANS, bool SK = false>
+template <int BM2, int BN, int NW, int WNW, int BKT, int NST, bool CONV, bool TRANS>
 __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void gemm2_kernel(const anip_gemm_params p,
                                                                                            const int skip_epilogue, const int splitk) {
   constexpr int NT2 = NW * 64;
@@ -477,15 +474,12 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
     // start the accumulators from the per-column additive terms (bias and, when the block's rows share one row group,
     // the row-group bias): NB small L2-resident loads that travel with the prologue DMA, no registers, and nothing
     // left to fetch for them in the epilogue, where loads queue behind the tile's stores (see there).
-    // (split-K with the in-kernel reduction: the slices start from zero and the LAST ARRIVER adds the terms to the reduced tile)
-    const bool sk_inkernel = SK && splitk > 1 && p.splitk_tickets != nullptr;
-    const bool bias_ok = !TRANS && (splitk <= 1 || sk_inkernel) && p.alpha == 1.0f && m0 + BM2 <= p.M && n0 + BN <= p.N &&
-                         (p.bias != nullptr || p.rowbias != nullptr) &&
-                         (p.rowbias == nullptr || (((p.ld_rowbias & 3) == 0) && ((((uintptr_t)p.rowbias) & 15) == 0)));
-    const bool acc_has_bias = bias_ok;      // true at the epilogue in both forms
+    const bool acc_has_bias = !TRANS && splitk <= 1 && p.alpha == 1.0f && m0 + BM2 <= p.M && n0 + BN <= p.N &&
+                              (p.bias != nullptr || p.rowbias != nullptr) &&
+                              (p.rowbias == nullptr || (((p.ld_rowbias & 3) == 0) && ((((uintptr_t)p.rowbias) & 15) == 0)));
     const bool rb_uni = acc_has_bias && p.rowbias != nullptr &&
                         (m0 / p.rows_per_group == (m0 + BM2 - 1) / p.rows_per_group);
-    auto add_col_terms = [&](bool init) {
+    if (!TRANS && acc_has_bias) {
       const float* rb_row = rb_uni ? p.rowbias + (int64_t)(m0 / p.rows_per_group) * p.ld_rowbias : nullptr;
 #pragma unroll
       for (int j = 0; j < NB; ++j) {
@@ -494,10 +488,9 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
         if (p.bias != nullptr) b = *(const f32x4*)(p.bias + cb);
         if (rb_uni) b += *(const f32x4*)(rb_row + cb);
 #pragma unroll
-        for (int i = 0; i < FM; ++i) acc[i][j] = init ? b : acc[i][j] + b;
+        for (int i = 0; i < FM; ++i) acc[i][j] = b;
       }
-    };
-    if (!TRANS && acc_has_bias && !sk_inkernel) add_col_terms(true);
+    }
 
     if constexpr (PHASED) {
       // K-tile 0 (issued in front of the tile loop / in front of the previous tile's epilogue) has landed for every wave;
@@ -623,94 +616,6 @@ __global__ __launch_bounds__(NW * 64, (WNW == 4 ? 2 : (NW == 8 ? 4 : 2))) void g
 #pragma unroll
         for (int j = 0; j < NB; ++j) asm volatile("" ::"v"(acc[i][j]));
       return;               // (ends a persistent walk, too)
-    }
-    if constexpr (SK) if (sk_inkernel) {
-      // ---- split-K, reduced INSIDE the launch (round 6; cdna_hip_programming.md §5 "in-launch split-K reduction", the
-      // Guideline-16 hand-off in its counter form).  Slice blockIdx.y of tile vb draws an arrival ticket; every slice but the
-      // last arriver publishes its fp32 accumulators — in REGISTER layout, fragment-major: one 1-KB run per wave and store —
-      // behind an agent-scope release and counts itself done; the last arriver, which keeps its own partial in registers,
-      // waits for the S - 1 publishers (they are running: a ticket holder is resident, so the wait is bounded and needs no
-      // co-scheduling assumption), acquires, and adds the slabs in SLICE order — the same sum whatever the arrival order
-      // (S == 2: a + b == b + a; S > 2: its own accumulators go through its slab, too, so that every term comes from memory
-      // in order) — then runs the ordinary epilogue.  Both counters return to zero for the next launch that is handed these
-      // words.  Placement-independent; a tile's slices share an XCD (and the slabs stay in its L2) when nblk % 8 == 0.
-      constexpr int FRAGS = FM * NB;
-      float* wsf = (float*)p.workspace;
-      const int64_t slab = (int64_t)FRAGS * NT2 * 4;                  // floats per (slice, tile)
-      int* tk = (int*)p.splitk_tickets + 2 * vb;                       // { arrived, published }
-      const int slice = (int)blockIdx.y;
-      // slabs through buffer descriptors: one VGPR (tid * 16) + a scalar fragment offset per access.  With flat pointers every
-      // one of the FM * NB fragment addresses is a 64-bit VGPR pair (their 8-KB steps do not fit an instruction offset) that
-      // the compiler computes up front: + 80 VGPRs next to 160 accumulator registers, and the wide tiles' main loop spills.
-      auto slab_rsrc = [&](int s_) {
-        return __builtin_amdgcn_make_buffer_rsrc((void*)(wsf + ((int64_t)s_ * nblk + vb) * slab), 0, (uint32_t)(slab * 4), 0x00020000);
-      };
-      const int tvo = tid * 16;
-      auto dump = [&](int s_) {
-        const auto rs = slab_rsrc(s_);
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int j = 0; j < NB; ++j) {
-            union { f32x4 f; u32x4 u; } c;
-            c.f = acc[i][j];
-            __builtin_amdgcn_raw_buffer_store_b128(c.u, rs, tvo, (i * NB + j) * NT2 * 16, 0);
-          }
-      };
-      __syncthreads();                                                 // every wave is through its last LDS read: smem is free
-      if (tid == 0) *(volatile int*)smem = __hip_atomic_fetch_add(tk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __syncthreads();
-      const int ticket = *(volatile int*)smem;
-      if (ticket != splitk - 1) {
-        dump(slice);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __hip_atomic_fetch_add(tk + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        return;
-      }
-      if (tid == 0) {
-        while (__hip_atomic_load(tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != splitk - 1) __builtin_amdgcn_s_sleep(4);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        __hip_atomic_store(tk, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(tk + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      __syncthreads();
-      // (one row of fragments — NB loads — in flight at a time)
-      auto add_slab = [&](int s_) {
-        const auto rs = slab_rsrc(s_);
-        int vo = tvo;
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-          f32x4 t[NB];
-#pragma unroll
-          for (int j = 0; j < NB; ++j) {
-            union { f32x4 f; u32x4 u; } c;
-            c.u = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (i * NB + j) * NT2 * 16, 0);
-            t[j] = c.f;
-          }
-#pragma unroll
-          for (int j = 0; j < NB; ++j) acc[i][j] += t[j];
-          // the next row's address "depends" on this row's last sum: the buffer-load intrinsics float above a plain
-          // memory-clobber asm, and with all FM * NB loads in flight the wide tiles have 160 + 160 live registers
-          asm volatile("" : "+v"(vo) : "v"(acc[i][NB - 1]));
-        }
-      };
-      if (splitk == 2) {
-        add_slab(slice ^ 1);
-      } else {
-        dump(slice);                    // own lanes read back what they wrote: program order, no fence
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < FM; ++i)
-#pragma unroll
-          for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int s_ = 0; s_ < splitk; ++s_) add_slab(s_);
-      }
-      if (!TRANS && acc_has_bias) add_col_terms(false);
     }
     float alpha = p.alpha;
     // what the accumulators already carry of the per-column additive terms (see acc_has_bias above)
@@ -1192,21 +1097,6 @@ int launch_gemm2(const anip_gemm_params& p, hipStream_t stream, int splitk = 1) 
     const unsigned ncu = (unsigned)gemm2_cu_count();
     if (ncu >= 8 && (ncu & 7) == 0 && grid > ncu) grid = ncu;
   }
-  if constexpr (!TRANS && ((NW == 4 && BKT == 32) || (NW == 8 && BKT == 64 && NST == 2))) {   // the four split configurations
-    if (splitk > 1 && p.splitk_tickets != nullptr) {
-      auto ksk = gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS, true>;
-      if (anip_raise_lds_limit((const void*)ksk, LDS) != 0) {
-        anip_set_error("anip_gemm: cannot raise the dynamic LDS limit to %d bytes", LDS);
-        return -2;
-      }
-      hipLaunchKernelGGL(ksk, dim3(grid, (unsigned)splitk, 1), dim3(NT2), LDS, stream, p, 0, splitk);
-      return 1;
-    }
-  }
-  if (splitk > 1 && p.splitk_tickets != nullptr) {
-    anip_set_error("anip_gemm: internal: in-launch split-K on a tile configuration without the reduction");
-    return -2;
-  }
   hipLaunchKernelGGL((gemm2_kernel<BM2, BN, NW, WNW, BKT, NST, CONV, TRANS>), dim3(grid, (unsigned)p.batch, 1),
                      dim3(NT2), LDS, stream, p, 0, splitk);
   return 1;
@@ -1272,45 +1162,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // split factor for problems with too few tiles to fill the chip (1 = no split); *cfg = tile configuration:
 // 128 / 160: 128-row 4-wave tiles of that width; 256 / 320: the wide 256-row tiles of that width
-// ANIP_SK_FORCE="<bn>:<S>" (experiments, read once): every eligible problem is split into S slices of the tile configuration bn
-// (128 / 160: 128-row 4-wave tiles; 256 / 320: the wide 256-row tiles) — how the split rules below were measured
-static bool sk_forced(int* bn, int* S) {
-  static int fbn = -1, fS = 0;
-  if (fbn < 0) {
-    fbn = 0;
-    const char* e = getenv("ANIP_SK_FORCE");
-    if (e != nullptr) {
-      int a = 0, b = 0;
-      if (sscanf(e, "%d:%d", &a, &b) == 2 && (a == 128 || a == 160 || a == 256 || a == 320) && b >= 1 && b <= 32) { fbn = a; fS = b; }
-    }
-  }
-  *bn = fbn; *S = fS;
-  return fbn > 0;
-}
-static int sk_rules() {      // ANIP_SK_RULES=0: the round-3..5 rules only (A/B measurements)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("ANIP_SK_RULES"); v = (e != nullptr && e[0] == '0') ? 0 : 1; }
-  return v;
-}
-
 static int gemm2_split(const anip_gemm_params& p, int* cfg) {
   if (p.batch > 1 || p.act == 1 || p.trans_out || p.M < 64 || p.M > 16384 || (p.N & 3) != 0) return 1;
   if (p.conv ? (p.Cin % 32 != 0) : (p.A2 != nullptr && (p.K1 % 32) != 0)) return 1;
   if ((((uintptr_t)p.bias | (uintptr_t)p.rowbias) & 15) != 0) return 1;
-  {
-    int fbn, fS;
-    if (sk_forced(&fbn, &fS)) {
-      const bool wide = fbn >= 256;
-      const bool k64 = p.conv ? (p.Cin % 64 == 0) : (p.A2 == nullptr || p.K1 % 64 == 0);
-      if (wide && !k64) return 1;
-      const int nk = (p.K + (wide ? 63 : 31)) / (wide ? 64 : 32);
-      int S = min(fS, nk / 2);
-      if (S < 2) return 1;
-      *cfg = fbn;
-      const int per = (nk + S - 1) / S;
-      return (nk + per - 1) / per;
-    }
-  }
   if (p.M < 1024) {
     // A handful of 128-row tiles under a long K: the once-per-clip ReferenceNet at its 8x8 / 16x16 levels (M = 128 / 512 for
     // the CFG pair of one reference frame; its 3x3 convolutions stream 29-59 MB of weights through 10 workgroups of the
@@ -1367,26 +1222,10 @@ static int gemm2_split(const anip_gemm_params& p, int* cfg) {
   return (nk + per - 1) / per;               // every slice non-empty
 }
 
-// tiles of the split configuration (the in-kernel reduction keeps one fp32 slab per (slice, tile), tile-padded, in register layout)
-static int64_t sk_tiles(const anip_gemm_params& p, int bn, int* bm_out) {
-  const int bm = bn >= 256 ? 256 : 128;
-  if (bm_out) *bm_out = bm;
-  return (int64_t)((p.M + bm - 1) / bm) * ((p.N + bn - 1) / bn);
-}
-
 int64_t anip_gemm2_workspace_bytes(const anip_gemm_params& p) {
-  int bn = 128, bm;
+  int bn;
   const int S = gemm2_split(p, &bn);
-  if (S <= 1) return 0;
-  const int64_t tiles = sk_tiles(p, bn, &bm);
-  return (int64_t)S * tiles * bm * bn * 4;       // >= S * M * N * 4, the [split][M][N] form of the two-pass path
-}
-
-// ints of zeroed device memory the in-kernel reduction wants in `splitk_tickets` (two per output tile), 0 if the problem is not split
-int64_t anip_gemm2_ticket_ints(const anip_gemm_params& p) {
-  int bn = 128;
-  const int S = gemm2_split(p, &bn);
-  return S > 1 ? 2 * sk_tiles(p, bn, nullptr) : 0;
+  return S > 1 ? (int64_t)S * p.M * p.N * 4 : 0;
 }
 
 // split-K path: 1 if launched (partials + reduce), 0 if the problem is not split, < 0 on error
@@ -1395,23 +1234,13 @@ int anip_gemm2_try_splitk(const anip_gemm_params& p, hipStream_t stream) {
   int bn = 128;
   const int S = gemm2_split(p, &bn);
   if (S <= 1) return 0;
-  const int64_t need = anip_gemm2_workspace_bytes(p);
+  const int64_t need = (int64_t)S * p.M * p.N * 4;
   if (p.workspace == nullptr || p.workspace_bytes < need || (((uintptr_t)p.workspace) & 15) != 0) {
     anip_set_error("anip_gemm: this problem is split over K and needs %lld bytes of 16-B aligned workspace "
                    "(anip_gemm_workspace_bytes); got %lld", (long long)need, (long long)p.workspace_bytes);
     return -1;
   }
-  if (p.splitk_tickets != nullptr) {
-    // reduced inside the launch by each tile's last-arriving slice, which then runs the ordinary epilogue (see the kernel)
-    if ((((uintptr_t)p.out | (uintptr_t)p.bias | (uintptr_t)p.residual) & 15) == 0 && (((uintptr_t)p.splitk_tickets) & 3) == 0) {
-      if (bn == 128) return dispatch_gemm2<128, 128, 4, 2, 32, 3>(p, stream, S);
-      if (bn == 160) return dispatch_gemm2<128, 160, 4, 2, 32, 3>(p, stream, S);
-      if (bn == 256) return dispatch_gemm2<256, 256, 8, 4, 64, 2>(p, stream, S);
-      return dispatch_gemm2<256, 320, 8, 4, 64, 2>(p, stream, S);
-    }
-  }
   anip_gemm_params q = p;
-  q.splitk_tickets = nullptr;
   q.out = p.workspace; q.ldo = p.N; q.out_f32 = 1;
   q.alpha = 1.0f; q.bias = nullptr; q.rowbias = nullptr; q.residual = nullptr;
   q.head_dim = 0;            // partial tiles are plain [split][M][N]; the reduce kernel applies the output mapping

@@ -328,41 +328,6 @@ def layernorm(x, gamma, beta, eps=1e-5, pe=None, rows_per_frame=0, frames=0):
     return y
 
 
-# ---- arrival counters of the in-launch split-K reduction (anip_gemm_params.splitk_tickets) --------------------------------
-# The library wants them ZERO at launch and leaves them zero; two launches that may run concurrently must not share them.
-#   eager launches: one small buffer per (device, stream) — launches of one stream are serialised;
-#   launches captured into a hipGraph: fresh words out of a monotonic arena, NEVER handed out twice — a graph's nodes keep their
-#   own words for the graph's lifetime, so graphs replayed side by side (ReferenceNet on the main stream, PoseGuider on the side
-#   stream) cannot collide with each other or with eager launches.  Arenas are created outside capture only (an allocation +
-#   fill inside a capture would become graph nodes); an exhausted arena during capture falls back to the two-pass reduction.
-_SK_INKERNEL = os.environ.get("ANIP_SPLITK_INKERNEL", "1") == "1"
-_SK_EAGER = {}
-_SK_ARENA = {}
-_SK_ARENA_INTS = 1 << 20
-_SK_EAGER_INTS = 1 << 14
-
-
-def _splitk_tickets(device, n):
-    if n <= 0:
-        return None
-    capturing = torch.cuda.is_current_stream_capturing()
-    if not capturing:
-        key = (str(device), torch.cuda.current_stream(device).cuda_stream)
-        buf = _SK_EAGER.get(key)
-        if buf is None:
-            buf = _SK_EAGER[key] = torch.zeros((_SK_EAGER_INTS,), dtype=torch.int32, device=device)
-        arena = _SK_ARENA.get(str(device))     # the arena of later captures: made (and renewed) here, where allocating is legal
-        if arena is None or arena[1] > _SK_ARENA_INTS * 3 // 4:     # (the old arena stays alive through the views graphs hold)
-            _SK_ARENA[str(device)] = [torch.zeros((_SK_ARENA_INTS,), dtype=torch.int32, device=device), 0]
-        return buf if n <= _SK_EAGER_INTS else None
-    arena = _SK_ARENA.get(str(device))
-    if arena is None or arena[1] + n > _SK_ARENA_INTS:
-        return None
-    view = arena[0][arena[1]:arena[1] + n]
-    arena[1] += (n + 3) // 4 * 4
-    return view
-
-
 def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None, act=0, out_f32=False,
          alpha=1.0, out=None, conv=None, batch=1, ldo=None, ldr=None, trans_out=False, head_dim=0, debug_ws=None):
     """out = epilogue(alpha * A @ W^T).
@@ -465,10 +430,6 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
         if wsb > 0:
             ws = torch.empty((wsb,), dtype=torch.uint8, device=A.device)
             p.workspace, p.workspace_bytes = _p(ws), wsb
-            if _SK_INKERNEL:     # reduced inside the launch by each tile's last-arriving slice (needs zeroed arrival counters)
-                tk = _splitk_tickets(A.device, int(lib.anip_gemm_splitk_ticket_ints(C.byref(p))))
-                if tk is not None:
-                    p.splitk_tickets = _p(tk)
     if debug_ws is not None:     # experiment builds only (segment-timing kernels write their counters here)
         p.workspace, p.workspace_bytes = _p(debug_ws), debug_ws.numel() * debug_ws.element_size()
     L.check(lib.anip_gemm(C.byref(p), _stream()), "anip_gemm")

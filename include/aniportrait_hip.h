@@ -107,15 +107,8 @@ typedef struct anip_gemm_params {
    * The K projection of anip_ref_attention (to_k of src/models/mutual_self_attention.py:147-165): a 64-key tile of one
    * head is then one contiguous run instead of 2 d-byte pieces at a C-byte stride. */
   int head_dim;
-  /* In-launch split-K reduction (round 6, ABI 15): device pointer to anip_gemm_splitk_ticket_ints(p) ints that are ZERO
-   * when the launch starts and are left zero when it ends (two arrival counters per output tile), not shared with any launch
-   * that may run concurrently.  With it a split problem is ONE launch: each slice publishes its fp32 tile into `workspace`
-   * behind an agent-scope release, the tile's last-arriving slice adds the slabs in slice order (bit-reproducible) and runs
-   * the whole epilogue; NULL keeps the two-pass form (partials + a reduce kernel). */
-  int* splitk_tickets;
 } anip_gemm_params;
 int64_t anip_gemm_workspace_bytes(const anip_gemm_params* p);
-int64_t anip_gemm_splitk_ticket_ints(const anip_gemm_params* p);
 int anip_gemm(const anip_gemm_params* p, void* stream);
 
 /* ---- fused GEGLU feed-forward (the engine's default at C = 320; ANIP_FUSED_FFN=0 selects two anip_gemm calls) -------

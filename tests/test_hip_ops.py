@@ -984,37 +984,6 @@ def test_gemm_split_k(M, N, K):
     close(out32, 0.5 * _ref_mm(A, W), f"gemm split-K f32 {M}x{N}x{K}", rtol=1e-3, arms=1e-3)
 
 
-@pytest.mark.parametrize("M,N,K,hd", [(2048, 1280, 5120, 0), (2048, 1280, 1280, 0), (8192, 1280, 1280, 160), (8192, 3840, 1280, 0),
-                                      (8192, 1280, 5120, 0), (1100, 1284, 4096, 0), (512, 1280, 5120, 0), (4096, 640, 2560, 80)])
-def test_gemm_split_k_reduced_in_the_launch(M, N, K, hd):
-    """Round 6: the split is ONE launch — every slice but a tile's last arriver publishes its fp32 accumulators behind an
-    agent-scope release, the last arriver adds the slabs in slice order and runs the whole epilogue (bias, row-group bias,
-    residual, alpha, fp32 / head-major output).  Checked: against fp32; bit-identical over repeated launches (the sum does not
-    depend on which slice arrives last) and to the two-pass form's tolerance; the arrival counters are zero again afterwards.
-    (Run the same test under ANIP_SK_FORCE=<bn>:<S> — tools/gpu_round6.sh sktests — to force every tile configuration.)"""
-    from aniportrait_amd import hipops as H
-    ops = _ops()
-    A = rnd(M, K, seed=220).to(DEV)
-    W = rnd(N, K, seed=221, scale=K ** -0.5).to(DEV)
-    bias = rnd(N, seed=222).float().to(DEV)
-    rowbias = rnd(4, N, seed=223).float().to(DEV)
-    res = rnd(M, N, seed=224).to(DEV)
-    idx = torch.arange(M) // ((M + 3) // 4)
-    ref = _ref_mm(A, W) + bias.cpu() + rowbias.cpu()[idx] + res.float().cpu()
-    outs = [ops.gemm(A, W, bias, rowbias=rowbias, rows_per_group=(M + 3) // 4, residual=res) for _ in range(6)]
-    close(outs[0], ref, f"gemm split-K in-launch {M}x{N}x{K}")
-    assert all(torch.equal(outs[0], o) for o in outs[1:]), "the in-launch reduction is not bit-reproducible"
-    out32 = ops.gemm(A, W, None, out_f32=True, alpha=0.5)
-    close(out32, 0.5 * _ref_mm(A, W), f"gemm split-K in-launch f32 {M}x{N}x{K}", rtol=1e-3, arms=1e-3)
-    if hd:
-        hm = ops.gemm(A, W, bias, head_dim=hd)
-        plain = ops.gemm(A, W, bias)
-        assert torch.equal(hm, plain.reshape(M, N // hd, hd).permute(1, 0, 2).contiguous())
-    torch.cuda.synchronize()
-    for buf in H._SK_EAGER.values():
-        assert int(buf.abs().max()) == 0, "arrival counters were not returned to zero"
-
-
 @pytest.mark.parametrize("Cin", [1280, 2560])
 def test_conv3x3_split_k(Cin):
     """the 8x8 level: 32 wide tiles -> up to 8 K-slices of 256 x 320 tiles (round 3), bias + time-embedding rows + residual

@@ -192,7 +192,7 @@ def main():
         bench_gemm(128, 1280, 1280, "refnet 8^2 out-proj", res=True)
         bench_gemm(128, 1280, 2560, "refnet 8^2 shortcut (concat)", a2=1280)
         bench_gemm(8192, 8192, 8192, "square 8k")
-    if "sk" in (only or ()):   # the tile-starved levels (round 6: split-K reduced inside the launch): ANIP_SK_FORCE=<bn>:<S> sweeps
+    if "sk" in (only or ()):   # the tile-starved levels (16x16 / 8x8: the shapes round 6's in-launch split-K experiment was measured on, profiles/r06/h_*)
         bench_gemm(NF * 256, 1280, 1280, "16^2 out-proj x4", res=True)
         bench_gemm(NF * 256, 1280, 1280, "16^2 proj_in / to_q")
         bench_gemm(NF * 256, 3840, 1280, "16^2 temporal qkv x2")

@@ -48,7 +48,7 @@ for STEP in "$@"; do
     N=${STEP#hbench:}
     ANIP_PIPE_TIMING=host timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-roofline --no-extra-configs --no-async-leg > $OUT/hbench_$N.log 2>&1; echo "rc=$?"
     grep "pipe timing" $OUT/hbench_$N.log | tail -n 10 | cut -c1-700 ;;
-  skbench:*)  # skbench:<name> — the tile-starved shapes under the current ANIP_SK_FORCE / ANIP_SPLITK_INKERNEL / ANIP_SK_RULES
+  skbench:*)  # skbench:<name> — the tile-starved shapes under the current environment
     N=${STEP#skbench:}
     timeout 300 python tools/bench_kernels.py --only=sk > $OUT/skbench_$N.jsonl 2>&1; echo "rc=$?"
     python - <<PY
@@ -59,11 +59,6 @@ for l in open("$OUT/skbench_$N.jsonl"):
     if "us" in r: print("%-8s %-36s %8.1f us %7.1f TF"%(r["kernel"][:8], r["tag"][:36], r["us"], r["tflops"]))
 PY
     ;;
-  sktests)    # the in-launch split-K reduction under every forced tile configuration
-    for F in "" 128:2 160:2 160:4 256:2 320:2 320:3 320:4 256:8; do
-      ANIP_SK_FORCE=$F timeout 600 python -m pytest tests/test_hip_ops.py -m gpu -q -k "split_k" > $OUT/sktests_$F.log 2>&1
-      echo "ANIP_SK_FORCE=$F: $(grep -E "passed|failed" $OUT/sktests_$F.log | tail -n 1)"; grep -E "^FAILED|Error" $OUT/sktests_$F.log | head -n 4
-    done ;;
   cputhreads) timeout 900 python tools/cpu_threads_probe.py 16 32 64 2>&1 | grep threads | tee $OUT/cpu_threads_probe.jsonl ;;
   gtests:*)   # gtests:<file>:<expr>  pytest tests/<file> -k "<expr>"
     AB=${STEP#gtests:}; Fi=${AB%%:*}; E=${AB#*:}; N=$(echo "$Fi$E" | tr -c 'a-zA-Z0-9_' '_')
