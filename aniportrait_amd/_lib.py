@@ -57,8 +57,6 @@ SIGNATURES = {
                                c_void_p]),
     "anip_ffn_geglu_ln": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_int64, c_int, c_void_p]),
-    "anip_conv_small": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
-                                c_int, c_void_p]),
     "anip_conv_direct": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                  c_int, c_int, c_int, c_int, c_void_p]),
     "anip_batchnorm_ws_floats": (c_int64, [c_int64, c_int]),

@@ -744,8 +744,7 @@ extern "C" int anip_temporal_attention(const void* qkv, void* out, int B, int F,
   const float sl2 = scale * 1.4426950408889634f;
   const int64_t blocks = (int64_t)B * T * (heads / hpg);
   ANIP_REQUIRE(blocks < (1ll << 31), "anip_temporal_attention: grid too large");
-  static const int mfma_off = getenv("ANIP_TEMPORAL_MFMA") ? (atoi(getenv("ANIP_TEMPORAL_MFMA")) == 0) : 0;   // A/B against the v_dot2 kernel
-  if (F == 16 && !mfma_off && (d == 40 || d == 80 || d == 160)) {
+  if (F == 16 && (d == 40 || d == 80 || d == 160)) {
     const int CG = hpg * d;
     const size_t lds16 = (size_t)2 * 16 * (CG * 2 + 16) + (size_t)(CG + 16) * 32;
     const unsigned nblk = (unsigned)blocks;

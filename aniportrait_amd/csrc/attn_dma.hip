@@ -479,8 +479,6 @@ int launch_dma(const RefAttnArgs& a, int Nf, hipStream_t stream) {
 }  // namespace
 
 int anip_ref_attn_dma_try(const RefAttnArgs& a, int Nf, int d, hipStream_t stream) {
-  static const int off = getenv("ANIP_ATTN_DMA") ? (atoi(getenv("ANIP_ATTN_DMA")) == 0) : 0;   // ANIP_ATTN_DMA=0: A/B against ref_attn_kernel
-  if (off) return 0;
   if (a.T % 256 != 0 || !a.vt_vec_ok || (a.ref_index != nullptr && !a.vtref_vec_ok)) return 0;
   const bool fits32 = (int64_t)a.T * a.ldk * 2 < (1ll << 31) && (int64_t)a.T * a.ldkr * 2 < (1ll << 31) &&
                       (int64_t)(d + 1) * a.ldvt * 2 < (1ll << 31) && (int64_t)(d + 1) * a.ldvtr * 2 < (1ll << 31);

@@ -8,63 +8,6 @@ namespace {
 constexpr int NT = 256;
 
 // ---------------------------------------------------------------------------------------------
-// direct conv, Cin <= 8 (conv_in, post_quant_conv). Weights cached in LDS (fp16).
-// thread -> (pixel, group of 8 output channels)
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void conv_small_kernel(const f16* __restrict__ x, const f16* __restrict__ w,
-                                                       const float* __restrict__ bias, const f16* __restrict__ res,
-                                                       f16* __restrict__ y, int N, int H, int W, int Cin, int Cout,
-                                                       int ks, int pix_per_block) {
-  extern __shared__ __attribute__((aligned(16))) f16 sw[];  // [Cout][ks*ks*Cin]
-  const int tid = threadIdx.x;
-  const int KK = ks * ks * Cin;
-  for (int i = tid; i < Cout * KK; i += NT) sw[i] = w[i];
-  __syncthreads();
-  const int cg_n = (Cout + 7) / 8;
-  const int64_t npix = (int64_t)N * H * W;
-  const int64_t pix0 = (int64_t)blockIdx.x * pix_per_block;
-  const int pad = ks / 2;
-  for (int o = tid; o < pix_per_block * cg_n; o += NT) {
-    const int pl = o / cg_n, cg = o - pl * cg_n;
-    const int64_t pix = pix0 + pl;
-    if (pix >= npix) continue;
-    const int xw = (int)(pix % W);
-    const int yh = (int)((pix / W) % H);
-    const int64_t img = pix / ((int64_t)W * H);
-    float acc[8];
-    const int co0 = cg * 8;
-    const int nco = min(8, Cout - co0);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = (bias != nullptr && e < nco) ? bias[co0 + e] : 0.f;
-    for (int ky = 0; ky < ks; ++ky) {
-      const int iy = yh + ky - pad;
-      if (iy < 0 || iy >= H) continue;
-      for (int kx = 0; kx < ks; ++kx) {
-        const int ix = xw + kx - pad;
-        if (ix < 0 || ix >= W) continue;
-        const f16* xp = x + ((img * H + iy) * W + ix) * Cin;
-        const int wk = (ky * ks + kx) * Cin;
-        for (int ci = 0; ci < Cin; ++ci) {
-          const float xv = (float)xp[ci];
-#pragma unroll
-          for (int e = 0; e < 8; ++e)
-            if (e < nco) acc[e] += xv * (float)sw[(co0 + e) * KK + wk + ci];
-        }
-      }
-    }
-    f16* yp = y + pix * Cout + co0;
-    const f16* rp = res ? res + pix * Cout + co0 : nullptr;
-#pragma unroll
-    for (int e = 0; e < 8; ++e)
-      if (e < nco) {
-        float v = acc[e];
-        if (rp) v += (float)rp[e];
-        yp[e] = (f16)v;
-      }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------
 // y[m][n] = sum_k f(x[m][k]) W[n][k] + b[n], M <= 16 (time-embedding MLP, the stacked time_emb_proj of all resnets,
 // collapsed attn2): a weight-streaming GEMV.  f(x) (SiLU or identity) is evaluated ONCE per block into LDS — round 4:
 // the first version applied it per output column, 51 M exp + rcp for the stacked projection (N = 20160, K = 1280, M = 2:
@@ -276,28 +219,6 @@ inline unsigned grid_for(int64_t work) {
 }
 
 }  // namespace
-
-extern "C" int anip_conv_small(const void* x, const void* w, const float* bias, const void* residual, void* y, int N,
-                               int H, int W, int Cin, int Cout, int ksize, void* stream) {
-  ANIP_REQUIRE(x && w && y, "anip_conv_small: null pointer");
-  ANIP_REQUIRE(ksize == 1 || ksize == 3, "anip_conv_small: ksize must be 1 or 3");
-  ANIP_REQUIRE(Cin >= 1 && Cin <= 8, "anip_conv_small: Cin=%d must be in [1,8]", Cin);
-  const size_t lds = (size_t)Cout * ksize * ksize * Cin * sizeof(f16);
-  ANIP_REQUIRE(lds <= 65536, "anip_conv_small: weights (%zu B) do not fit in LDS", lds);
-  const int cg_n = (Cout + 7) / 8;
-  int ppb = (NT * 8) / cg_n;  // ~8 outputs groups per thread
-  if (ppb < 1) ppb = 1;
-  if (ppb > 1024) ppb = 1024;
-  const int64_t npix = (int64_t)N * H * W;
-  const int64_t blocks = cdiv64(npix, ppb);
-  {
-    AnipProfScope prof_(ANIP_K_CONV_SMALL, (void*)stream);
-    hipLaunchKernelGGL(conv_small_kernel, dim3((unsigned)blocks), dim3(NT), lds, (hipStream_t)stream, (const f16*)x,
-                       (const f16*)w, bias, (const f16*)residual, (f16*)y, N, H, W, Cin, Cout, ksize, ppb);
-  }
-  ANIP_LAUNCH_CHECK("anip_conv_small");
-  return 0;
-}
 
 extern "C" int anip_linear_small(const float* x, const void* W, const float* bias, float* y, int M, int N, int K,
                                  int silu_in, void* stream) {

@@ -82,13 +82,6 @@ class PackedNet:
             self.t[k] = ops.pack_conv3x3(self._raw(name).to(self.device, F16))
         return self.t[k]
 
-    def conv_small(self, name):
-        """tiny-Cin conv weight -> fp16 [Cout][k][k][Cin]."""
-        k = ("convs", name)
-        if k not in self.t:
-            self.t[k] = self._raw(name).to(self.device, F16).permute(0, 2, 3, 1).contiguous()
-        return self.t[k]
-
     def conv_direct(self, name):
         """small-channel conv weight -> fp16 [k*k*Cin][Cout8] (LDS image of anip_conv_direct)."""
         k = ("convd", name)

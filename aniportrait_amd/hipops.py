@@ -490,20 +490,6 @@ def conv3x3(x, Wp, bias, stride=1, pad=1, upsample=False, pad_hi=None, rowbias=N
     return out.reshape(N, Ho, Wo, Wp.shape[0])
 
 
-def conv_small(x, w, bias, ksize, residual=None):
-    """x (N, H, W, Cin<=8) fp16, w (Cout, k, k, Cin) fp16 -> (N, H, W, Cout) (stride 1, same padding)."""
-    lib = L.load()
-    _req(x, F16, "x")
-    _req(w, F16, "w")
-    N, H, Wd, Cin = x.shape
-    Cout = w.shape[0]
-    y = torch.empty((N, H, Wd, Cout), dtype=F16, device=x.device)
-    _work(K_CONV_SMALL, x.numel() * 2 + y.numel() * 2, f"small N{N} {H}x{Wd} Cin{Cin} Cout{Cout} k{ksize}")
-    L.check(lib.anip_conv_small(_p(x), _p(w), _p(bias), _p(residual), _p(y), N, H, Wd, Cin, Cout, ksize, _stream()),
-            "anip_conv_small")
-    return y
-
-
 def pack_conv_direct(w):
     """torch conv weight [Cout, Cin, k, k] -> [k*k*Cin, Cout8] (tap-major, output channel fastest, Cout padded
     with zeros to a multiple of 8): the LDS image of anip_conv_direct."""

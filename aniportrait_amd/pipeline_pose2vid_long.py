@@ -724,14 +724,26 @@ class Pose2VideoPipeline(_Base):
 
         def finish(host):
             if output_type == "uint8":
-                return host.clone() if async_output else host
+                return host.clone() if (async_output or host.is_pinned()) else host
             images = host.float().numpy()       # fp32 up-cast on the host, after the fp16 D2H (reference order)
             return torch.from_numpy(images) if output_type == "tensor" else images
 
         if async_output:
             images = self._to_host_async(video, finish)
         else:
-            host = video.cpu()
+            # through ONE recycled pinned buffer per shape (round 6): a pageable `.cpu()` of the 25-MB clip is a staged copy of
+            # 3-5 ms with the GPU idle behind it; pinned, the same bytes cross in ~0.6 ms.  The buffer never leaves this function:
+            # `finish` copies out of it (fp32 up-cast, or a clone of the display bytes)
+            if video.is_cuda:
+                stage = self.__dict__.setdefault("_sync_pinned", {})
+                key = (tuple(video.shape), video.dtype)
+                host = stage.get(key)
+                if host is None:
+                    stage.clear()
+                    host = stage[key] = torch.empty(video.shape, dtype=video.dtype, pin_memory=True)
+                host.copy_(video)
+            else:
+                host = video.cpu()
             tm.mark("d2h")
             images = finish(host)
         tm.mark("d2h+float")

@@ -125,13 +125,6 @@ int anip_ffn_geglu(const void* x, const void* w1p, const float* b1p, const void*
 int anip_ffn_geglu_ln(const void* x, const float* gamma, const float* beta, float eps, const void* w1p, const float* b1p,
                       const void* w2, const float* b2, const void* residual, void* out, int64_t M, int C, void* stream);
 
-/* ---- small-channel direct convolution (Cin or Cout not MFMA-shaped) -----------------------------
- * conv_in 4->C (src/models/unet_3d.py:90-92,484), AutoencoderKL post_quant_conv / decoder.conv_in.
- * x [N,H,W,Cin] fp16, w [Cout][k][k][Cin] fp16, bias fp32, optional residual [N,H,W,Cout] fp16
- * (pose feature add, unet_3d.py:485-486), y fp16.  ksize 1 or 3, stride 1, pad ksize/2. */
-int anip_conv_small(const void* x, const void* w, const float* bias, const void* residual, void* y,
-                    int N, int H, int W, int Cin, int Cout, int ksize, void* stream);
-
 /* ---- PoseGuider stem: direct convolution + BatchNorm2d(+ReLU) --------------------------------------
  * replaces the nn.Conv2d / nn.BatchNorm2d / nn.ReLU stacks of src/models/pose_guider.py:19-85 whose channel
  * counts (3, 16, 32) or 4x4-stride-2 windows do not fit the implicit-GEMM kernel.

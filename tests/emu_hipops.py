@@ -160,14 +160,6 @@ def conv3x3(x, Wp, bias, stride=1, pad=1, upsample=False, pad_hi=None, rowbias=N
     return out.reshape(N, Ho, Wo, Wp.shape[0])
 
 
-def conv_small(x, w, bias, ksize, residual=None):
-    y = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), None if bias is None else bias.float(),
-                 padding=ksize // 2).permute(0, 2, 3, 1)
-    if residual is not None:
-        y = y + residual.float()
-    return y.to(F16).contiguous()
-
-
 def conv_direct(x, wp, bias, Cout, ksize, stride=1, pad=1, relu=False, residual=None):
     Cin = x.shape[-1]
     w = wp.float()[:, :Cout].reshape(ksize, ksize, Cin, Cout).permute(3, 2, 0, 1)
@@ -311,7 +303,7 @@ def f16_to_u8(src, scale=1.0, shift=0.0):
     return ((src.float() * scale + shift).clamp(0, 1).to(F16).float() * 255.0).to(torch.uint8)
 
 
-_EMULATED = ("groupnorm", "layernorm", "rowgemm320_supported", "groupnorm_scale_shift", "affine_linear320", "ln_qkv_projection", "gemm", "ffn_geglu", "ffn_geglu_ln", "conv3x3", "conv_small", "conv_direct", "batchnorm", "ref_attention",
+_EMULATED = ("groupnorm", "layernorm", "rowgemm320_supported", "groupnorm_scale_shift", "affine_linear320", "ln_qkv_projection", "gemm", "ffn_geglu", "ffn_geglu_ln", "conv3x3", "conv_direct", "batchnorm", "ref_attention",
              "temporal_attention", "temporal_qkv_attention", "temporal_qkv_attention_supported", "softmax_rows", "linear_small", "add", "window_accumulate", "cfg_ddim_step",
              "ncfhw_to_nhwc", "nhwc_to_ncfhw", "u8_to_f16", "f16_to_u8")
 

@@ -182,20 +182,6 @@ def test_conv3x3_rowbias_residual():
     close(out, ref, "conv3x3 + temb rowbias + residual")
 
 
-@pytest.mark.parametrize("Cin,Cout,ks", [(4, 320, 3), (4, 4, 1), (4, 512, 3), (3, 64, 3)])
-def test_conv_small(Cin, Cout, ks):
-    ops = _ops()
-    N, H, W = 2, 9, 11
-    x = rnd(N, H, W, Cin, seed=30).to(DEV)
-    w = rnd(Cout, Cin, ks, ks, seed=31, scale=0.3)
-    b = rnd(Cout, seed=32).float()
-    res = rnd(N, H, W, Cout, seed=33).to(DEV)
-    wp = w.permute(0, 2, 3, 1).contiguous().to(DEV)
-    out = ops.conv_small(x, wp, b.to(DEV), ks, residual=res)
-    ref = F.conv2d(x.float().cpu().permute(0, 3, 1, 2), w.float(), b, padding=ks // 2).permute(0, 2, 3, 1) + res.float().cpu()
-    close(out, ref, f"conv_small {Cin}->{Cout} k{ks}")
-
-
 # ------------------------------------------------------------------------------------------------
 # norms
 # ------------------------------------------------------------------------------------------------

@@ -144,8 +144,7 @@ def bench_temporal(B, F, T, heads, d, tag):
 
 def main():
     """--only gemm,conv,attn,norm   restrict the families;   --cold   cache-cold launches (see _flush);   env switches of the library (read once per process) make
-    one invocation = one kernel variant: ANIP_ATTN_DMA=0 / ANIP_TEMPORAL_MFMA=0 (the first-generation attention kernels),
-    ANIP_LIB=<experiment build>; OPERANDS_ZERO=1 / ATTN_ZERO=1: all-zero operands (clock / power check)."""
+    one invocation = one kernel variant: ANIP_LIB=<experiment build>; OPERANDS_ZERO=1 / ATTN_ZERO=1: all-zero operands (clock / power check)."""
     import os
     global COLD, BOTH
     only = None
