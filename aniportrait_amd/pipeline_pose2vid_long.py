@@ -363,7 +363,12 @@ class Pose2VideoPipeline(_Base):
         state-dict like a foreign AutoencoderKL; re-adopted when the module is replaced, moved or re-typed)"""
         src = self.image_encoder
         p = next(src.parameters())
-        tag = (id(src), str(p.device), p.dtype, p.data_ptr(), p._version)
+        # every parameter's storage address and in-place version (ADVICE r5: keying on the first parameter alone would keep
+        # serving stale packed weights after a partial module swap / LoRA merge); ~400 tensors, tens of microseconds
+        sig = 0
+        for q in src.parameters():
+            sig = (sig * 1000003 + q.data_ptr() + 7919 * q._version) & 0xFFFFFFFFFFFF
+        tag = (id(src), str(p.device), p.dtype, sig)
         cur = self.__dict__.get("_hip_clip_state")
         if cur is None or cur[0] != tag:
             from .clip_vision import CLIPVisionHip
