@@ -746,11 +746,14 @@ class Pose2VideoPipeline(_Base):
             video = None if frames is None else (frames if u8 else frames.permute(1, 0, 2, 3).unsqueeze(0))
         else:
             video = self._decode_nhwc(z, 1, decode_chunk, u8)
-        if _GC_CONTROL and not gc.isenabled():
-            gc.collect()        # the host's idle point: everything of this clip is queued (see _run)
         if video is None:
+            if _GC_CONTROL and not gc.isenabled():
+                gc.collect()
             return None
         tm.mark("vae_decode")
+        if _GC_CONTROL and not gc.isenabled():
+            gc.collect()        # the host's idle point: everything of this clip is queued (see _run); ~0.1 s of host time that
+            tm.mark("gc(host idle)")   # the un-instrumented call spends under the GPU's queue — only the synchronised stage line shows it
 
         def finish(host):
             if output_type == "uint8":
