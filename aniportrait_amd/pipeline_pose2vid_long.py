@@ -751,7 +751,9 @@ class Pose2VideoPipeline(_Base):
                 gc.collect()
             return None
         tm.mark("vae_decode")
-        if _GC_CONTROL and not gc.isenabled():
+        # (only behind a queue that can hide it: ~0.1 s of host time against >= ~0.2 s of queued GPU work; a small clip leaves
+        #  collection to the interpreter, which resumes it when the call returns)
+        if _GC_CONTROL and not gc.isenabled() and L * h * w * len(timesteps) * len(windows) >= 16 * 32 * 32 * 10:
             gc.collect()        # the host's idle point: everything of this clip is queued (see _run); ~0.1 s of host time that
             tm.mark("gc(host idle)")   # the un-instrumented call spends under the GPU's queue — only the synchronised stage line shows it
 

@@ -104,3 +104,19 @@ def test_split_k_decision_is_host_logic_and_covers_the_small_m_problems():
     # the denoising UNet: 8x8 convolutions (M = 2048, K = 11 520) on up to 8 slices of the wide tiles; chip-filling shapes unsplit
     assert 2 <= slices(ws(2048, 1280, 11520, conv=(32, 8, 1280)), 2048, 1280) <= 8
     assert ws(8192, 1280, 1280) == 0 and ws(131072, 320, 320) == 0 and ws(32768, 640, 2560) == 0
+
+
+def test_ref_attention_wrapper_validates_the_frame_modulus():
+    """frame_mod travels in bits 16.. of a C int — the wrapper refuses values that would wrap, a frame count that is
+    not a multiple of it, and operands that do not hold `frame_mod` frames (checked before any pointer reaches the library)"""
+    import pytest
+    import torch
+
+    from aniportrait_amd import hipops
+    T, heads, d = 4, 2, 8
+    q = torch.zeros((2 * T, heads * d), dtype=torch.float16)
+    k = torch.zeros_like(q)
+    vt = torch.zeros((heads * d, 2 * T), dtype=torch.float16)
+    for kw in (dict(n_frames=4, frame_mod=40000), dict(n_frames=5, frame_mod=2), dict(n_frames=6, frame_mod=3)):
+        with pytest.raises(ValueError):
+            hipops.ref_attention(q, heads * d, k, heads * d, vt, 2 * T, kw["n_frames"], T, heads, d, frame_mod=kw["frame_mod"])
