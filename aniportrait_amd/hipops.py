@@ -334,7 +334,8 @@ def gemm(A, W, bias=None, A2=None, rowbias=None, rows_per_group=0, residual=None
 
     A (M, K) fp16 [+ A2 (M, K2): K split over two sources]; W (N, K) fp16; bias (N,) fp32;
     rowbias (M/rows_per_group, N) fp32 (row stride = rowbias.stride(0): a column slice of a wider
-    table is fine); residual (M, N) fp16; act=1 -> GEGLU (W packed by pack_geglu).
+    table is fine); residual (M, N) fp16; act=1 -> GEGLU (W packed by pack_geglu); act=2 -> quick-GELU
+    x * sigmoid(1.702 x) on (alpha acc + bias + rowbias), ahead of the residual (CLIP's MLP).
     A / W may be column slices of wider row-major matrices (row stride = .stride(-2)).
     conv: dict(Nimg, Hin, Win, Cin, Hout, Wout, stride, pad, upsample) -> A is the NHWC image batch.
     batch > 1: A (B, M, K) or (M, K) shared; W (B, N, K) or (N, K) shared -> out (B, M, N).
