@@ -10,11 +10,11 @@ import os
 import torch
 
 
-def cpu_quota():
+def cpu_quota(root="/sys/fs/cgroup"):
     """CPUs the cgroup grants this process (cgroup v2 `cpu.max`, v1 `cpu.cfs_quota_us / cpu.cfs_period_us`), or None if
     unlimited / unknown"""
     try:
-        with open("/sys/fs/cgroup/cpu.max") as f:
+        with open(os.path.join(root, "cpu.max")) as f:
             q, p = f.read().split()[:2]
         if q != "max" and float(p) > 0:
             return max(1.0, float(q) / float(p))
@@ -22,9 +22,9 @@ def cpu_quota():
     except (OSError, ValueError):
         pass
     try:
-        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+        with open(os.path.join(root, "cpu", "cpu.cfs_quota_us")) as f:
             q = float(f.read())
-        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+        with open(os.path.join(root, "cpu", "cpu.cfs_period_us")) as f:
             p = float(f.read())
         return max(1.0, q / p) if q > 0 and p > 0 else None
     except (OSError, ValueError):

@@ -222,3 +222,37 @@ def test_aux_graph_cache_is_bounded_and_follows_the_packed_weights():
     assert sum(1 for k in pipe.__dict__["_aux_graphs"] if k[0] == "refnet") == 1
     pipe.drop_cached_graphs()
     assert pipe.__dict__["_aux_graphs"] == {}
+
+
+def test_host_cpu_budget_follows_the_cgroup_quota(tmp_path, monkeypatch):
+    """aniportrait_amd/hostcfg.py (round 6): the MI355X box's container grants 16 CPUs (`cpu.max = 1600000 100000`) under 256
+    visible cores; a torch pool sized by the latter gets the process throttled for 50-90 ms at a time"""
+    import torch
+
+    from aniportrait_amd import hostcfg
+    (tmp_path / "cpu.max").write_text("1600000 100000\n")
+    assert hostcfg.cpu_quota(str(tmp_path)) == 16.0
+    (tmp_path / "cpu.max").write_text("max 100000\n")
+    assert hostcfg.cpu_quota(str(tmp_path)) is None
+    v1 = tmp_path / "v1"
+    (v1 / "cpu").mkdir(parents=True)
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("400000")
+    (v1 / "cpu" / "cpu.cfs_period_us").write_text("100000")
+    assert hostcfg.cpu_quota(str(v1)) == 4.0
+    (v1 / "cpu" / "cpu.cfs_quota_us").write_text("-1")
+    assert hostcfg.cpu_quota(str(v1)) is None
+    assert hostcfg.cpu_quota(str(tmp_path / "nowhere")) is None
+    # the cap: only downwards, never past an explicit choice of the application
+    before = torch.get_num_threads()
+    try:
+        monkeypatch.delenv("OMP_NUM_THREADS", raising=False)
+        monkeypatch.setenv("ANIP_HOST_THREADS", "0")
+        assert hostcfg.bound_host_threads(force=True) == before
+        monkeypatch.setenv("ANIP_HOST_THREADS", "2")
+        assert hostcfg.bound_host_threads(force=True) == 2
+        monkeypatch.delenv("ANIP_HOST_THREADS")
+        monkeypatch.setattr(hostcfg, "usable_cpus", lambda: 4)
+        torch.set_num_threads(before)
+        assert hostcfg.bound_host_threads(limit=8, force=True) == min(before, 2)
+    finally:
+        torch.set_num_threads(before)
