@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define ANIP_ABI_VERSION 15
+#define ANIP_ABI_VERSION 15   /* 15 (round 6): anip_gemm act = 2 (quick-GELU); anip_conv_small removed */
 
 int anip_version(void);
 const char* anip_last_error(void);
