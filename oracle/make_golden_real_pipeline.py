@@ -48,6 +48,8 @@ def run_case(models, name):
     def cb(step, t, lat):
         lat_steps.append(lat.detach().clone().half())
         print(f"  {name}: step {step} (t={int(t)}) done at {time.time() - t0:.0f} s", flush=True)
+        # hours-long cases: keep what exists (an interrupted run is finished by `--finish <name>`, below)
+        torch.save(dict(latents_f16=torch.stack(lat_steps), seconds=time.time() - t0), os.path.join(GOLD, f".partial_{name}.pt"))
 
     vid = pipe(i["ref_image"], list(i["poses"]), i["ref_pose"], i["W"], i["H"], i["L"], i["steps"], i["cfg"],
                generator=torch.manual_seed(i["gen_seed"]), callback=cb).videos
@@ -62,8 +64,36 @@ def run_case(models, name):
     return out
 
 
+@torch.no_grad()
+def finish_case(models, name):
+    """An interrupted run whose DDIM loop completed (every step's latents are in tests/golden/.partial_<name>.pt): decode the
+    stored frames with the reference's own `decode_latents` arithmetic (pipeline_pose2vid_long.py:113-126: 1 / 0.18215, the
+    VAE frame by frame, / 2 + 0.5, clamp) — the pipeline decodes every frame independently, so decoding only the stored ones
+    gives the same bytes — and compute the CLIP embedding as `run_case` does."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from golden_inputs import real_pipe_inputs
+    i = real_pipe_inputs(name)
+    part = torch.load(os.path.join(GOLD, f".partial_{name}.pt"))
+    lat = part["latents_f16"]
+    assert lat.shape[0] == i["steps"], f"only {lat.shape[0]} of {i['steps']} steps were completed"
+    final = lat[-1].float()                                   # (1, 4, L, h, w): what the pipeline hands to decode_latents
+    fr = list(i["frames"])
+    frames = []
+    for k in fr:
+        z = final[:, :, k] / 0.18215
+        frames.append((models["vae"].decode(z).sample / 2 + 0.5).clamp(0, 1)[0])
+    u8 = (torch.stack(frames).permute(0, 2, 3, 1) * 255.0).round().clamp(0, 255).to(torch.uint8).contiguous()
+    from transformers import CLIPImageProcessor
+    clip = models["image_encoder"](CLIPImageProcessor().preprocess(
+        i["ref_image"].resize((224, 224)), return_tensors="pt").pixel_values).image_embeds
+    return dict(latents_f16=lat, frames_u8=u8, frames=torch.tensor(fr), video_mean=torch.stack(frames).double().mean().float(),   # (of the stored frames only)
+                clip_embeds=clip.float(), seconds=float(part["seconds"]), finished_from_partial=True)
+
+
 def main():
-    names = sys.argv[1:] or ["l40_windows"]
+    args = sys.argv[1:]
+    finish = "--finish" in args
+    names = [a for a in args if not a.startswith("--")] or ["l40_windows"]
     R.setup()
     from transformers import CLIPVisionConfig, CLIPVisionModelWithProjection
 
@@ -73,8 +103,11 @@ def main():
     enc = CLIPVisionModelWithProjection(CLIPVisionConfig(**dict(C.CLIP_SMALL, projection_dim=768)))
     m["image_encoder"] = fill_module_(enc, 0, "image_encoder768.").eval()   # tests/util.py clip_encoder_for(False)
     for name in names:
-        res = run_case(m, name)
+        res = finish_case(m, name) if finish else run_case(m, name)
         torch.save(res, os.path.join(GOLD, f"real_pipeline_{name}.pt"))
+        part = os.path.join(GOLD, f".partial_{name}.pt")
+        if os.path.isfile(part):
+            os.remove(part)
 
 
 if __name__ == "__main__":
