@@ -241,9 +241,8 @@ def test_c4_long_clip_150_frames_four_steps_vs_reference_fixture(real_pipe):
     window of step k + 1 starts from, so an error in the overlap / wrap-around accumulate compounds instead of showing once.
     Against the reference's own pipeline on PyTorch-CPU fp32 (oracle/make_golden_real_pipeline.py c4_4step, ~40 CPU-minutes per
     step): the latents of all 150 frames after every step the fixture holds (overall and per frame >= 40 dB), and — when the
-    recipe ran to its end — six decoded frames (PSNR >= 40 dB).  The committed fixture may hold the first three steps only
-    (`steps_completed`: the build container's session was interrupted three times inside the fourth; the recipe now checkpoints
-    every step and `--finish`es from there)."""
+    recipe ran to its end — six decoded frames (PSNR >= 40 dB).  (A fixture may hold fewer steps: the build container's sessions
+    were interrupted repeatedly, the recipe checkpoints every step and `--finish`es from there; the committed one is complete.)"""
     pipe, _ = real_pipe
     vid, lats, gold, i = _fixture_case(pipe, "c4_4step")
     n_ref = int(gold["latents_f16"].shape[0])
